@@ -1,0 +1,198 @@
+/*
+ * include/trg_engine.h -- C ABI of the MI355X-native Traversal-Risk-Graph construction engine.
+ *
+ * This is the drop-in boundary for the one hot path this repository accelerates: everything the
+ * reference's `class TRG` does between "here is a point-cloud map" and "here is the graph"
+ * (reference: cpp/trg_planner/core/trg_planner/include/graph/trg.h:50-98 and
+ * src/graph/trg.cpp).  Plain pointers and sizes only; no C++/torch types; no exceptions cross
+ * the boundary; every call returns a TrgStatus and trg_engine_last_error() explains failures.
+ *
+ * Each entry point cites the reference interface it replaces.  The C++ `TRG`/`TRGPlanner`
+ * shims, the Python mirror (trg-planner_amd/trg_planner) and the reference-side binding shown
+ * in INTEGRATION.md are thin layers over exactly these symbols.
+ *
+ * Threading: like the reference (every entry is taken under TRG::mtx.graph, trg.cpp:37,196,458,610)
+ * an engine must be entered from one thread at a time; one HIP stream set per engine.
+ */
+#ifndef TRG_ENGINE_H_
+#define TRG_ENGINE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct TrgEngine TrgEngine;
+
+typedef enum TrgStatus {
+  TRG_OK = 0,
+  TRG_ERR_INVALID_ARG = 1,
+  TRG_ERR_NO_MAP = 2,        /* reference: assert "Map is empty", trg.cpp:42 */
+  TRG_ERR_NO_ROOT = 3,       /* reference: "Failed to generate root node" + exit(1), trg.cpp:49-52 */
+  TRG_ERR_DEVICE = 4,        /* HIP runtime error, no GPU, wrong architecture */
+  TRG_ERR_NO_GRAPH = 5,
+  TRG_ERR_NOT_FOUND = 6,     /* planSafePath returned false, trg.cpp:689 */
+  TRG_ERR_IO = 7,
+  TRG_ERR_CAPACITY = 8
+} TrgStatus;
+
+/* Graph / map selector: reference trgMap_ keys "global" / "local" (trg.h:113-119).
+ * TRG_KIND_PRECLEAN is build-side instrumentation: the global graph as it stood right before
+ * the last cleanGraph(), ids == creation order (used by the parity tests). */
+typedef enum TrgKind { TRG_KIND_GLOBAL = 0, TRG_KIND_LOCAL = 1, TRG_KIND_PRECLEAN = 2 } TrgKind;
+
+/* Node states: reference TRG::NodeState, trg.h:27-31 */
+enum { TRG_NODE_VALID = 0, TRG_NODE_INVALID = -1, TRG_NODE_FRONTIER = 1 };
+
+/* Constructor arguments of reference TRG::TRG, trg.h:51-59 / trg.cpp:11-34 (same order). */
+typedef struct TrgParams {
+  int32_t is_verbose;
+  float expand_dist;
+  float robot_size;
+  int32_t sample_num;
+  float height_threshold;
+  float collision_threshold;
+  float update_collision_threshold;
+  float safety_factor;
+  float goal_tolerance;
+} TrgParams;
+
+/* The reference seeds std::mt19937 from std::random_device (trg.cpp:20), so it has no canonical
+ * sample stream; here the sampler is an explicit input.  Direction of trial t of the expansion
+ * of node id in build epoch e = table[hash(seed, e, id, t) >> (32 - table_bits)], table[k] =
+ * (cosf, sinf)((float)(k / 2^bits * 2 * M_PI)) computed once with the host libm (same values the
+ * reference's `distr_(gen_) * 2 * M_PI` -> cos/sin would give for that draw, trg.cpp:395-397). */
+typedef struct TrgSampler {
+  uint32_t seed;
+  int32_t table_bits; /* 8..20, default 16 */
+} TrgSampler;
+
+/* Read-only view of a built graph in CSR form (host memory owned by the engine, valid until the
+ * next call that mutates that graph).  Replaces the std::unordered_map<int, Node*> the reference
+ * hands out (TRG::getGraph / getGraphCopy, trg.cpp:805-824): row i is the node with id_ == i,
+ * col/weight/dist are that node's edges_ in order (Edge{dst_id_, weight_, dist_}, trg.h:20-25). */
+typedef struct TrgCsrView {
+  int32_t num_nodes;
+  int32_t num_edges;        /* directed edges = CSR nnz */
+  const float *node_xyz;    /* num_nodes x 3, Node::pos_ */
+  const int32_t *node_state;/* num_nodes, Node::state_ */
+  const int32_t *rowptr;    /* num_nodes + 1 */
+  const int32_t *col;       /* num_edges, Edge::dst_id_ */
+  const float *weight;      /* num_edges, Edge::weight_ */
+  const float *dist;        /* num_edges, Edge::dist_ */
+  const int32_t *creation_id; /* num_nodes: index of the node in creation order of the last build */
+} TrgCsrView;
+
+/* Output of trg_engine_plan: reference TRG::planSafePath out-params (trg.cpp:603-608). */
+typedef struct TrgPathInfo {
+  float direct_dist;
+  float path_length;
+  float avg_risk;
+  int32_t num_points;
+} TrgPathInfo;
+
+/* Counters and timers of the last build (instrumentation; bench.py's roofline uses them). */
+typedef struct TrgStats {
+  uint64_t map_points;
+  uint64_t expanded_nodes;     /* nodes popped from the BFS queue */
+  uint64_t trials;             /* sample draws */
+  uint64_t samples;            /* accepted samples */
+  uint64_t created_nodes;
+  uint64_t invalid_nodes;
+  uint64_t edge_calls;         /* wireEdge() calls replayed */
+  uint64_t edge_evals_gpu;     /* edge evaluations executed on the GPU (speculative ones included) */
+  uint64_t nn_ties;            /* fp32 distance ties seen by nearest-neighbour queries */
+  uint64_t gate_uncertain;     /* slope gates decided by host libm atan2f */
+  uint64_t sync_batches;       /* synchronous GPU round trips forced by the replay */
+  /* bytes of map points inside query radii that the GPU kernels touched (12 B per hit) */
+  uint64_t bytes_sample_kernel;
+  uint64_t bytes_edge_kernel;
+  uint64_t bytes_index_build;
+  /* device time per kernel family, milliseconds, measured with hipEvents on the launch stream */
+  double ms_index_build;
+  double ms_sample_kernel;
+  double ms_edge_kernel;
+  uint64_t launches_sample_kernel;
+  uint64_t launches_edge_kernel;
+  /* host wall time, milliseconds */
+  double ms_set_map_total;
+  double ms_init_graph_total;
+  double ms_replay_host;
+  double ms_finalize_host;
+  double ms_wait_gpu;
+} TrgStats;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* reference: TRG::TRG(...) trg.cpp:11-34.  device = HIP device ordinal. */
+TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out);
+void trg_engine_destroy(TrgEngine *e);
+const char *trg_engine_last_error(const TrgEngine *e);
+/* "gfx950" etc. of the device the engine runs on */
+const char *trg_engine_device_arch(const TrgEngine *e);
+
+/* ---- map ingest ------------------------------------------------------------------------------ */
+/* reference: TRG::setGlobalMap(PointCloudPtr&) trg.cpp:179-193 (the kd_insert2 loop becomes the
+ * cell-sorted SoA index build on the GPU).  xyz: n points, `stride` floats apart (3 for packed
+ * xyz, 4 for pcl::PointXYZ). */
+TrgStatus trg_engine_set_global_map(TrgEngine *e, const float *xyz, size_t n, size_t stride);
+/* same, points already resident in device memory (HBM) */
+TrgStatus trg_engine_set_global_map_device(TrgEngine *e, const float *d_xyz, size_t n, size_t stride);
+/* reference: TRG::setLocalMap(Vector2f start2d, PointCloudPtr&) trg.cpp:195-209 (also refreshes
+ * the local graph membership, trg.cpp:211-231) */
+TrgStatus trg_engine_set_local_map(TrgEngine *e, const float start_xy[2], const float *xyz, size_t n,
+                                   size_t stride);
+/* reference: TRG::resetMap / TRG::resetGraph, trg.cpp:732-744 */
+TrgStatus trg_engine_reset_map(TrgEngine *e, TrgKind kind);
+TrgStatus trg_engine_reset_graph(TrgEngine *e, TrgKind kind);
+
+/* ---- graph build ----------------------------------------------------------------------------- */
+/* reference: TRG::initGraph(bool isPreMap, Vector3f start3d) trg.cpp:36-64
+ * (root seeding -> expandGraph :372-454 -> cleanGraph(false) :491-535). */
+TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const TrgSampler *sampler);
+/* reference: TRG::updateGraph() trg.cpp:456-489 */
+TrgStatus trg_engine_update_graph(TrgEngine *e);
+
+/* ---- export ---------------------------------------------------------------------------------- */
+/* reference: TRG::getGraph / getGraphCopy trg.cpp:805-824 */
+TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out);
+/* reference: TRG::saveGraph / loadPrebuiltGraph trg.cpp:66-177 (same JSON schema) */
+TrgStatus trg_engine_save_json(TrgEngine *e, const char *path);
+TrgStatus trg_engine_load_json(TrgEngine *e, const char *path);
+
+/* ---- query (host A*, consumes the CSR) ------------------------------------------------------- */
+/* reference: TRG::planSafePath trg.cpp:603-690 (+ setGoal :537-565).  path_xyz receives up to
+ * max_points x 3 floats; info->num_points is the full length. */
+TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goal_xyz[3],
+                          float *path_xyz, int32_t max_points, TrgPathInfo *info);
+/* reference: TRG::refinePath trg.cpp:692-730.  Returns the number of output points. */
+int32_t trg_engine_refine_path(const float *in_xyz, int32_t n_in, float *out_xyz, int32_t max_out);
+
+/* ---- batched probes of the pure map functions (debug / parity tests) ------------------------- */
+/* reference: TRG::isCollision(pos, type, threshold) trg.cpp:746-778.  Any output may be NULL.
+ * flag: 1 = collision; cnt: points with |z - z_med| > height_threshold; n: points in the disc. */
+TrgStatus trg_engine_is_collision_batch(TrgEngine *e, TrgKind map, float threshold, const float *xy,
+                                        size_t m, int32_t *flag, int32_t *cnt, int32_t *n);
+/* reference: the kd_nearest2 elevation lookup of TRG::addNode trg.cpp:244-247 */
+TrgStatus trg_engine_nearest_z_batch(TrgEngine *e, TrgKind map, const float *xy, size_t m, float *z);
+/* reference: the position-only part of TRG::wireEdge trg.cpp:269-363.
+ * status: 0 ok, 1 slope gate, 2 segment collision, 3 empty gather, 4 fewer than 3 points. */
+TrgStatus trg_engine_edge_risk_batch(TrgEngine *e, TrgKind map, const float *p1_xyz,
+                                     const float *p2_xyz, size_t m, int32_t *status, int32_t *n_pts,
+                                     float *weight, float *dist);
+/* reference: TRG::isFrontier trg.cpp:780-803 */
+TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, int32_t *flag);
+
+/* ---- instrumentation ------------------------------------------------------------------------- */
+TrgStatus trg_engine_get_stats(const TrgEngine *e, TrgStats *out);
+/* the direction table the engine uses (2^table_bits entries each) */
+TrgStatus trg_engine_get_sampler_table(TrgEngine *e, float *cos_out, float *sin_out);
+/* cell-sorted map arrays (n each), for index-build tests; any pointer may be NULL */
+TrgStatus trg_engine_debug_map_index(TrgEngine *e, TrgKind map, float *x, float *y, float *z,
+                                     int32_t *perm, int32_t *grid_wh, float *origin_cell);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRG_ENGINE_H_ */

@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "trg-planner_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oa():
+    """The CPU oracle wrapper (test infrastructure)."""
+    import oracle_api
+    oracle_api.build()
+    return oracle_api
+
+
+@pytest.fixture(scope="session")
+def synth():
+    from trg_planner import synth as s
+    return s
+
+
+@pytest.fixture(scope="session")
+def mountain_small(synth):
+    # 30 m x 30 m, 90 k points, rough enough to exercise gate / collision / clamp branches
+    return synth.mountain_cloud(300, 300, seed=11, amplitude=5.0, wavelength=14.0)
+
+
+@pytest.fixture(scope="session")
+def mountain_gentle(synth):
+    return synth.mountain_cloud(300, 300, seed=5)
+
+
+@pytest.fixture(scope="session")
+def indoor_small(synth):
+    pts, boxes = synth.indoor_cloud(seed=1, size=(16.0, 12.0), n_boxes=5)
+    return synth.voxel_centroids(pts, 0.2)
+
+
+def assert_graph_equal(g_engine, g_oracle, weight_tol=1e-5, allow_weight_outliers=0):
+    """Bit-exact structure (ids, CSR, states, xyz, dist); weights within weight_tol."""
+    assert g_engine.V == g_oracle.V, (g_engine.V, g_oracle.V)
+    assert g_engine.E == g_oracle.E, (g_engine.E, g_oracle.E)
+    assert np.array_equal(g_engine.rowptr, g_oracle.rowptr)
+    assert np.array_equal(g_engine.col, g_oracle.col)
+    assert np.array_equal(g_engine.state, g_oracle.state)
+    assert np.array_equal(g_engine.xyz.view(np.uint32), g_oracle.xyz.view(np.uint32))
+    assert np.array_equal(g_engine.dist.view(np.uint32), g_oracle.dist.view(np.uint32))
+    assert np.array_equal(g_engine.cid, g_oracle.cid)
+    if g_engine.E:
+        dw = np.abs(g_engine.w.astype(np.float64) - g_oracle.w.astype(np.float64))
+        bad = int((dw > weight_tol).sum())
+        assert bad <= allow_weight_outliers, (bad, float(dw.max()))

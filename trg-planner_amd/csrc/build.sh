@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds the gfx950 engine library in-tree: trg-planner_amd/csrc/libtrg_engine.so
+# (hipcc cross-compiles without a GPU).  -ffp-contract=off is part of the correctness contract:
+# every fp32 decision must round exactly like the reference's non-FMA x86-64 build.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wall -Wno-unused-function"
+mkdir -p "$HERE/_obj"
+"$HIPCC" $FLAGS -c "$HERE/trg_kernels.hip" -o "$HERE/_obj/trg_kernels.o" "$@"
+"$HIPCC" $FLAGS -c "$HERE/trg_engine.cpp" -o "$HERE/_obj/trg_engine.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/_obj/trg_kernels.o" "$HERE/_obj/trg_engine.o" -o "$HERE/libtrg_engine.so"
+echo "built $HERE/libtrg_engine.so"

@@ -1,0 +1,1876 @@
+// trg_engine.cpp -- host side of the MI355X TRG construction engine and its C ABI
+// (include/trg_engine.h).
+//
+// Division of labour:
+//   GPU  : every function of (positions, map) -- map index build, isCollision, elevation lookup,
+//          rejection sampling, edge risk (segment walk + ellipse gather + PCA).  trg_kernels.hip
+//   host : everything that depends on graph STATE and is inherently sequential in the reference --
+//          the FIFO of expandGraph (trg.cpp:376-381), nearest existing node / merge test
+//          (trg.cpp:408-417), wireEdge's dedupe (trg.cpp:255-267), cleanGraph's renumbering
+//          (trg.cpp:491-535), A* (trg.cpp:603-690).  The host never evaluates a map query itself:
+//          without a working HIP device every entry point fails with TRG_ERR_DEVICE.
+//
+// The BFS is replayed in exactly the reference's order; GPU work is issued ahead of the replay in
+// chunks of queued nodes (the samples of a node depend only on its position and id), so device
+// latency hides behind the host loop.
+#include <hip/hip_runtime.h>
+#include <math.h>  // float overloads of atan2 etc. in the global namespace, as the reference has
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <queue>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/trg_engine.h"
+#include "host_index.h"
+#include "trg_kernels.h"
+
+namespace {
+
+using namespace trg;
+using Clock = std::chrono::steady_clock;
+
+inline double ms_since(Clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+}
+inline float norm2f(float dx, float dy) { return sqrtf(dx * dx + dy * dy); }
+
+struct DevMap {
+  size_t n = 0;
+  float *x = nullptr, *y = nullptr, *z = nullptr;
+  int *perm = nullptr, *cell_start = nullptr;
+  size_t cap_pts = 0, cap_cells = 0;
+  MapView view{};
+  float g = 0;
+  float bounds[4] = {0, 0, 0, 0};
+  bool valid = false;
+};
+
+template <typename T>
+struct PinnedBuf {
+  T *h = nullptr;
+  T *d = nullptr;
+  size_t cap = 0;
+};
+
+// results of one speculative / deferred edge evaluation as the replay consumes them
+struct CallRec {
+  int n1, n2;
+  int status;  // EDGE_* | flags, -1 = pending
+  float weight, dist;
+};
+
+struct EdgePool {
+  std::vector<int> dst, next;
+  std::vector<float> w, dist;
+  std::vector<int> head, tail, deg;
+  void reset(size_t nodes) {
+    dst.clear();
+    next.clear();
+    w.clear();
+    dist.clear();
+    head.assign(nodes, -1);
+    tail.assign(nodes, -1);
+    deg.assign(nodes, 0);
+  }
+  void grow_nodes(size_t nodes) {
+    if (head.size() < nodes) {
+      head.resize(nodes, -1);
+      tail.resize(nodes, -1);
+      deg.resize(nodes, 0);
+    }
+  }
+  bool has(int a, int b) const {
+    for (int e = head[a]; e >= 0; e = next[e])
+      if (dst[e] == b) return true;
+    return false;
+  }
+  void push(int a, int b, float ww, float dd) {
+    const int e = (int)dst.size();
+    dst.push_back(b);
+    w.push_back(ww);
+    dist.push_back(dd);
+    next.push_back(-1);
+    if (tail[a] >= 0) {
+      next[tail[a]] = e;
+    } else {
+      head[a] = e;
+    }
+    tail[a] = e;
+    deg[a]++;
+  }
+};
+
+struct Csr {
+  std::vector<float> xyz;
+  std::vector<int32_t> state, rowptr, col, cid;
+  std::vector<float> w, dist;
+  void clear() {
+    xyz.clear();
+    state.clear();
+    rowptr.clear();
+    col.clear();
+    cid.clear();
+    w.clear();
+    dist.clear();
+  }
+};
+
+struct Chunk {
+  int first = 0, count = 0;  // queue positions [first, first+count)
+  bool in_flight = false;
+  hipEvent_t done = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;  // sample start / sample end / edges end
+  // inputs
+  PinnedBuf<float> node_xy, node_xyz;
+  PinnedBuf<int> node_id;
+  // outputs
+  PinnedBuf<int> n_acc, n_draws, status, n_pts;
+  PinnedBuf<float> sx, sy, sz, weight, dist;
+};
+
+struct EdgeBatch {
+  bool in_flight = false;
+  int count = 0;
+  hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
+  std::vector<int> call_idx;  // which CallRec each row fills
+  PinnedBuf<float> p1, p2, weight, dist;
+  PinnedBuf<int> status, n_pts;
+};
+
+}  // namespace
+
+struct TrgEngine {
+  TrgParams prm{};
+  int device = 0;
+  std::string err;
+  std::string arch;
+  bool device_ok = false;
+
+  hipStream_t s_main = nullptr, s_edge = nullptr;
+  DevMap gmap, lmap;
+  DeviceCounters *d_ctr = nullptr;
+  unsigned *d_bounds = nullptr;
+
+  // sampler
+  TrgSampler sampler{1, 16};
+  std::vector<float> cos_t, sin_t;
+  float *d_cos = nullptr, *d_sin = nullptr;
+  int table_bits_dev = 0;
+  uint32_t epoch = 0;
+
+  // graph state: slot == id (ids are dense at all times)
+  std::vector<float> nx, ny, nz;
+  std::vector<int> nstate;
+  std::vector<int> ncid;  // creation index inside the last build
+  std::unordered_map<int, int> order_map;  // mirrors trgStruct::nodes (iteration order only)
+  EdgePool edges;
+  int node_id = 0;
+  float root_pos[2] = {0, 0};
+  float local_root[2] = {0, 0};
+  std::unordered_map<int, int> local_map;  // mirrors local trgStruct::nodes (iteration order)
+  std::vector<int> local_nodes;  // ids in local_map's iteration order
+  NodeGrid grid;
+  NodeKd kd;          // reference-shaped index of the CURRENT global node set
+  bool kd_valid = false;
+  std::vector<int> kd_insert_order;  // ids in the order the reference inserted them
+  NodeKd lkd;         // local node tree (isFrontier does not use it; kept for completeness)
+  bool step3 = false;
+
+  // build scratch
+  std::vector<int> queue;
+  std::vector<CallRec> calls;
+  static constexpr int NCHUNK = 3;
+  static constexpr int CHUNK_MAX = 4096;
+  Chunk chunks[NCHUNK];
+  static constexpr int NEBATCH = 3;
+  static constexpr int EBATCH_MAX = 1 << 16;
+  EdgeBatch ebatches[NEBATCH];
+  std::vector<int> pending_calls;
+  int chunk_S = 0;
+
+  // small synchronous scratch
+  PinnedBuf<float> sy_in, sy_in2, sy_f0, sy_f1;
+  PinnedBuf<int> sy_i0, sy_i1, sy_i2;
+  size_t sy_cap = 0;
+
+  Csr csr_global, csr_pre, csr_local;
+  bool keep_preclean = true;
+  TrgStats stats{};
+
+  // goal state (trg.h:121-126)
+  int goal_node = -1;
+  bool goal_known = false;
+  float goal_pose2d[2] = {0, 0};
+
+  TrgStatus fail(TrgStatus s, const std::string &m) {
+    err = m;
+    return s;
+  }
+};
+
+namespace {
+
+#define HIPCHK(e, expr)                                                                   \
+  do {                                                                                    \
+    hipError_t _err = (expr);                                                             \
+    if (_err != hipSuccess) {                                                             \
+      return (e)->fail(TRG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_err)); \
+    }                                                                                     \
+  } while (0)
+
+template <typename T>
+hipError_t alloc_pinned(PinnedBuf<T> &b, size_t cap) {
+  if (b.cap >= cap) return hipSuccess;
+  if (b.h) (void)hipHostFree(b.h);
+  if (b.d) (void)hipFree(b.d);
+  b.h = nullptr;
+  b.d = nullptr;
+  b.cap = 0;
+  hipError_t e = hipHostMalloc((void **)&b.h, cap * sizeof(T), hipHostMallocDefault);
+  if (e != hipSuccess) return e;
+  e = hipMalloc((void **)&b.d, cap * sizeof(T));
+  if (e != hipSuccess) return e;
+  b.cap = cap;
+  return hipSuccess;
+}
+template <typename T>
+void free_pinned(PinnedBuf<T> &b) {
+  if (b.h) (void)hipHostFree(b.h);
+  if (b.d) (void)hipFree(b.d);
+  b.h = nullptr;
+  b.d = nullptr;
+  b.cap = 0;
+}
+
+QueryParams qparams(const TrgEngine *e) {
+  QueryParams q;
+  q.robot_size = e->prm.robot_size;
+  q.height_threshold = e->prm.height_threshold;
+  q.collision_threshold = e->prm.collision_threshold;
+  q.expand_dist = e->prm.expand_dist;
+  q.sample_num = e->prm.sample_num;
+  return q;
+}
+
+void free_map(DevMap &m) {
+  if (m.x) (void)hipFree(m.x);
+  if (m.y) (void)hipFree(m.y);
+  if (m.z) (void)hipFree(m.z);
+  if (m.perm) (void)hipFree(m.perm);
+  if (m.cell_start) (void)hipFree(m.cell_start);
+  m = DevMap();
+}
+
+inline float key_to_float(unsigned k) {
+  unsigned b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+}
+
+// ---- map index build ---------------------------------------------------------------------------
+TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_t stride) {
+  auto t_host = Clock::now();
+  m.valid = false;
+  if (n == 0) {
+    m.n = 0;
+    return TRG_OK;
+  }
+  if (n > (size_t)0x7FFFFFF0) return e->fail(TRG_ERR_CAPACITY, "more than 2^31 map points");
+  hipStream_t s = e->s_main;
+  hipEvent_t ev0, ev1;
+  HIPCHK(e, hipEventCreate(&ev0));
+  HIPCHK(e, hipEventCreate(&ev1));
+  HIPCHK(e, hipEventRecord(ev0, s));
+  launch_init_bounds(e->d_bounds, s);
+  launch_bounds(d_xyz, n, stride, e->d_bounds, s);
+  unsigned hb[4];
+  HIPCHK(e, hipMemcpyAsync(hb, e->d_bounds, sizeof(hb), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  const float x0 = key_to_float(hb[0]), y0 = key_to_float(hb[1]);
+  const float x1 = key_to_float(hb[2]), y1 = key_to_float(hb[3]);
+  if (!(x1 >= x0) || !(y1 >= y0) || !std::isfinite(x0) || !std::isfinite(x1) ||
+      !std::isfinite(y0) || !std::isfinite(y1)) {
+    return e->fail(TRG_ERR_INVALID_ARG, "map has non-finite coordinates");
+  }
+  // cell size = robot_size: a collision disc touches a 3x3 block, an edge ellipse <= 7x7
+  float g = e->prm.robot_size;
+  if (!(g > 0)) g = 0.3f;
+  const double max_cells = 64.0 * 1024 * 1024;
+  while (((double)(x1 - x0) / g + 2) * ((double)(y1 - y0) / g + 2) > max_cells) g *= 2.0f;
+  const float inv_g = 1.0f / g;
+  const int W = (int)floorf((x1 - x0) * inv_g) + 1;
+  const int H = (int)floorf((y1 - y0) * inv_g) + 1;
+  const size_t ncell = (size_t)W * H;
+
+  if (m.cap_pts < n) {
+    if (m.x) (void)hipFree(m.x);
+    if (m.y) (void)hipFree(m.y);
+    if (m.z) (void)hipFree(m.z);
+    if (m.perm) (void)hipFree(m.perm);
+    m.x = m.y = m.z = nullptr;
+    m.perm = nullptr;
+    HIPCHK(e, hipMalloc((void **)&m.x, n * sizeof(float)));
+    HIPCHK(e, hipMalloc((void **)&m.y, n * sizeof(float)));
+    HIPCHK(e, hipMalloc((void **)&m.z, n * sizeof(float)));
+    HIPCHK(e, hipMalloc((void **)&m.perm, n * sizeof(int)));
+    m.cap_pts = n;
+  }
+  if (m.cap_cells < ncell + 1) {
+    if (m.cell_start) (void)hipFree(m.cell_start);
+    m.cell_start = nullptr;
+    HIPCHK(e, hipMalloc((void **)&m.cell_start, (ncell + 1) * sizeof(int)));
+    m.cap_cells = ncell + 1;
+  }
+  int *d_cell_of = nullptr, *d_rank = nullptr, *d_counts = nullptr, *d_tmp = nullptr;
+  HIPCHK(e, hipMalloc((void **)&d_cell_of, n * sizeof(int)));
+  HIPCHK(e, hipMalloc((void **)&d_rank, n * sizeof(int)));
+  HIPCHK(e, hipMalloc((void **)&d_counts, ncell * sizeof(int)));
+  HIPCHK(e, hipMalloc((void **)&d_tmp, (ncell / 2048 + 4) * sizeof(int)));
+  HIPCHK(e, hipMemsetAsync(d_counts, 0, ncell * sizeof(int), s));
+  launch_cell_count(d_xyz, n, stride, x0, y0, inv_g, W, H, d_cell_of, d_rank, d_counts, s);
+  launch_exclusive_scan(d_counts, m.cell_start, (int)ncell, d_tmp, s);
+  launch_scatter(d_xyz, n, stride, d_cell_of, d_rank, m.cell_start, m.x, m.y, m.z, m.perm, s);
+  launch_cell_sort((int)ncell, m.cell_start, m.x, m.y, m.z, m.perm, s);
+  HIPCHK(e, hipEventRecord(ev1, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  HIPCHK(e, hipGetLastError());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ev0, ev1);
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  (void)hipFree(d_cell_of);
+  (void)hipFree(d_rank);
+  (void)hipFree(d_counts);
+  (void)hipFree(d_tmp);
+
+  m.n = n;
+  m.g = g;
+  m.bounds[0] = x0;
+  m.bounds[1] = y0;
+  m.bounds[2] = x1;
+  m.bounds[3] = y1;
+  m.view.x = m.x;
+  m.view.y = m.y;
+  m.view.z = m.z;
+  m.view.perm = m.perm;
+  m.view.cell_start = m.cell_start;
+  m.view.x0 = x0;
+  m.view.y0 = y0;
+  m.view.inv_g = inv_g;
+  m.view.W = W;
+  m.view.H = H;
+  m.view.n = (int)n;
+  m.valid = true;
+  if (&m == &e->gmap) {
+    e->stats.map_points = n;
+    e->stats.ms_index_build = ms;
+    // read xyz once, write the cell-sorted SoA once, cell ids once
+    e->stats.bytes_index_build = (uint64_t)(12 + 12 + 4) * n;
+    e->stats.ms_set_map_total = ms_since(t_host);
+  }
+  return TRG_OK;
+}
+
+TrgStatus upload_and_build(TrgEngine *e, DevMap &m, const float *xyz, size_t n, size_t stride) {
+  if (n == 0) {
+    m.n = 0;
+    m.valid = false;
+    return TRG_OK;
+  }
+  float *d_in = nullptr;
+  HIPCHK(e, hipMalloc((void **)&d_in, n * stride * sizeof(float)));
+  hipError_t he = hipMemcpy(d_in, xyz, n * stride * sizeof(float), hipMemcpyHostToDevice);
+  if (he != hipSuccess) {
+    (void)hipFree(d_in);
+    return e->fail(TRG_ERR_DEVICE, std::string("hipMemcpy map: ") + hipGetErrorString(he));
+  }
+  TrgStatus st = build_map(e, m, d_in, n, stride);
+  (void)hipFree(d_in);
+  return st;
+}
+
+// ---- sampler table -----------------------------------------------------------------------------
+TrgStatus ensure_sampler(TrgEngine *e, const TrgSampler *smp) {
+  TrgSampler want = smp ? *smp : e->sampler;
+  if (want.table_bits < 8 || want.table_bits > 20) want.table_bits = 16;
+  e->sampler = want;
+  if (e->table_bits_dev == want.table_bits && e->d_cos) return TRG_OK;
+  const size_t n = (size_t)1 << want.table_bits;
+  e->cos_t.resize(n);
+  e->sin_t.resize(n);
+  for (size_t k = 0; k < n; ++k) {
+    // the reference's `float angle = distr_(gen_) * 2 * M_PI; cos(angle), sin(angle)` (trg.cpp:395-397)
+    float u = (float)k / (float)n;
+    float angle = u * 2 * M_PI;
+    e->cos_t[k] = cos(angle);
+    e->sin_t[k] = sin(angle);
+  }
+  if (e->d_cos) (void)hipFree(e->d_cos);
+  if (e->d_sin) (void)hipFree(e->d_sin);
+  e->d_cos = e->d_sin = nullptr;
+  HIPCHK(e, hipMalloc((void **)&e->d_cos, n * sizeof(float)));
+  HIPCHK(e, hipMalloc((void **)&e->d_sin, n * sizeof(float)));
+  HIPCHK(e, hipMemcpy(e->d_cos, e->cos_t.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(e->d_sin, e->sin_t.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  e->table_bits_dev = want.table_bits;
+  return TRG_OK;
+}
+
+inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+inline uint32_t sample_hash(uint32_t seed, uint32_t epoch, uint32_t id, uint32_t trial) {
+  uint32_t h = fmix32(seed ^ 0x9E3779B9u);
+  h = fmix32(h + epoch * 0x9E3779B9u + 0x7F4A7C15u);
+  h = fmix32(h + id * 0x85EBCA6Bu + 0x165667B1u);
+  h = fmix32(h + trial * 0xC2B2AE35u + 0x27D4EB2Fu);
+  return h;
+}
+inline float sampler_uniform(const TrgEngine *e, uint32_t k) {
+  uint32_t h = sample_hash(e->sampler.seed, e->epoch, 0xFFFFFFFFu, k);
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---- synchronous probes ------------------------------------------------------------------------
+TrgStatus ensure_sync_scratch(TrgEngine *e, size_t m) {
+  if (e->sy_cap >= m) return TRG_OK;
+  size_t cap = std::max<size_t>(m, 1024);
+  HIPCHK(e, alloc_pinned(e->sy_in, cap * 3));
+  HIPCHK(e, alloc_pinned(e->sy_in2, cap * 3));
+  HIPCHK(e, alloc_pinned(e->sy_f0, cap));
+  HIPCHK(e, alloc_pinned(e->sy_f1, cap));
+  HIPCHK(e, alloc_pinned(e->sy_i0, cap));
+  HIPCHK(e, alloc_pinned(e->sy_i1, cap));
+  HIPCHK(e, alloc_pinned(e->sy_i2, cap));
+  e->sy_cap = cap;
+  return TRG_OK;
+}
+
+DevMap *pick_map(TrgEngine *e, TrgKind k) { return k == TRG_KIND_LOCAL ? &e->lmap : &e->gmap; }
+
+TrgStatus collision_sync(TrgEngine *e, DevMap &m, float threshold, const float *xy, size_t cnt,
+                         int32_t *flag, int32_t *c_out, int32_t *n_out) {
+  if (!m.valid) {
+    // empty map: kd_nearest_range on an empty tree returns no hits -> collision (trg.cpp:749-752)
+    for (size_t i = 0; i < cnt; ++i) {
+      if (flag) flag[i] = 1;
+      if (c_out) c_out[i] = 0;
+      if (n_out) n_out[i] = 0;
+    }
+    return TRG_OK;
+  }
+  const size_t B = 1 << 20;
+  for (size_t off = 0; off < cnt; off += B) {
+    const size_t m_ = std::min(B, cnt - off);
+    TrgStatus st = ensure_sync_scratch(e, m_);
+    if (st != TRG_OK) return st;
+    memcpy(e->sy_in.h, xy + 2 * off, m_ * 2 * sizeof(float));
+    HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 2 * sizeof(float), hipMemcpyHostToDevice,
+                             e->s_main));
+    launch_probe_collision(m.view, qparams(e), threshold, e->sy_in.d, (int)m_, e->sy_i0.d,
+                           e->sy_i1.d, e->sy_i2.d, e->d_ctr, e->s_main);
+    HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipMemcpyAsync(e->sy_i1.h, e->sy_i1.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipMemcpyAsync(e->sy_i2.h, e->sy_i2.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipStreamSynchronize(e->s_main));
+    HIPCHK(e, hipGetLastError());
+    if (flag) memcpy(flag + off, e->sy_i0.h, m_ * sizeof(int));
+    if (c_out) memcpy(c_out + off, e->sy_i1.h, m_ * sizeof(int));
+    if (n_out) memcpy(n_out + off, e->sy_i2.h, m_ * sizeof(int));
+  }
+  e->stats.sync_batches++;
+  return TRG_OK;
+}
+
+TrgStatus nearest_z_sync(TrgEngine *e, DevMap &m, const float *xy, size_t cnt, float *z,
+                         int32_t *found) {
+  if (!m.valid) return e->fail(TRG_ERR_NO_MAP, "nearest_z on an empty map");
+  const size_t B = 1 << 20;
+  for (size_t off = 0; off < cnt; off += B) {
+    const size_t m_ = std::min(B, cnt - off);
+    TrgStatus st = ensure_sync_scratch(e, m_);
+    if (st != TRG_OK) return st;
+    memcpy(e->sy_in.h, xy + 2 * off, m_ * 2 * sizeof(float));
+    HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 2 * sizeof(float), hipMemcpyHostToDevice,
+                             e->s_main));
+    launch_probe_nearest_z(m.view, qparams(e), e->sy_in.d, (int)m_, e->sy_f0.d, e->sy_i0.d,
+                           e->d_ctr, e->s_main);
+    HIPCHK(e, hipMemcpyAsync(e->sy_f0.h, e->sy_f0.d, m_ * sizeof(float), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipStreamSynchronize(e->s_main));
+    HIPCHK(e, hipGetLastError());
+    memcpy(z + off, e->sy_f0.h, m_ * sizeof(float));
+    if (found) memcpy(found + off, e->sy_i0.h, m_ * sizeof(int));
+  }
+  e->stats.sync_batches++;
+  return TRG_OK;
+}
+
+// The reference's slope gate (trg.cpp:269-274) evaluated with the host libm, used only for the
+// sliver the device's exact rational test could not decide.
+inline bool host_slope_gate(const TrgEngine *e, float z1, float z2, float dist) {
+  float max_slope = atan2(e->prm.height_threshold, e->prm.robot_size);
+  float slope = atan2(fabs(z1 - z2), dist);
+  return slope > max_slope;
+}
+// final status code (0..4) of an edge evaluation after resolving an uncertain gate
+inline int resolve_status(TrgEngine *e, int raw, float z1, float z2, float dist) {
+  if (raw & EDGE_GATE_UNCERTAIN) {
+    e->stats.gate_uncertain++;
+    if (host_slope_gate(e, z1, z2, dist)) return EDGE_GATE;
+  }
+  return raw & EDGE_STATUS_MASK;
+}
+
+TrgStatus edges_sync(TrgEngine *e, DevMap &m, const float *p1, const float *p2, size_t cnt,
+                     int32_t *status, int32_t *n_pts, float *weight, float *dist, bool resolve) {
+  if (!m.valid) return e->fail(TRG_ERR_NO_MAP, "edge evaluation on an empty map");
+  const size_t B = 1 << 18;
+  for (size_t off = 0; off < cnt; off += B) {
+    const size_t m_ = std::min(B, cnt - off);
+    TrgStatus st = ensure_sync_scratch(e, m_);
+    if (st != TRG_OK) return st;
+    memcpy(e->sy_in.h, p1 + 3 * off, m_ * 3 * sizeof(float));
+    memcpy(e->sy_in2.h, p2 + 3 * off, m_ * 3 * sizeof(float));
+    HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 3 * sizeof(float), hipMemcpyHostToDevice,
+                             e->s_main));
+    HIPCHK(e, hipMemcpyAsync(e->sy_in2.d, e->sy_in2.h, m_ * 3 * sizeof(float),
+                             hipMemcpyHostToDevice, e->s_main));
+    launch_edges(m.view, qparams(e), e->sy_in.d, e->sy_in2.d, (int)m_, e->sy_i0.d, e->sy_i1.d,
+                 e->sy_f0.d, e->sy_f1.d, e->d_ctr, e->s_main);
+    HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipMemcpyAsync(e->sy_i1.h, e->sy_i1.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipMemcpyAsync(e->sy_f0.h, e->sy_f0.d, m_ * sizeof(float), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipMemcpyAsync(e->sy_f1.h, e->sy_f1.d, m_ * sizeof(float), hipMemcpyDeviceToHost,
+                             e->s_main));
+    HIPCHK(e, hipStreamSynchronize(e->s_main));
+    HIPCHK(e, hipGetLastError());
+    for (size_t i = 0; i < m_; ++i) {
+      int raw = e->sy_i0.h[i];
+      int stt = raw;
+      if (resolve) {
+        stt = resolve_status(e, raw, p1[3 * (off + i) + 2], p2[3 * (off + i) + 2], e->sy_f1.h[i]);
+      }
+      if (status) status[off + i] = stt;
+      if (n_pts) n_pts[off + i] = e->sy_i1.h[i];
+      if (weight) weight[off + i] = (stt == EDGE_OK) ? e->sy_f0.h[i] : 0.0f;
+      if (dist) dist[off + i] = e->sy_f1.h[i];
+    }
+    e->stats.edge_evals_gpu += m_;
+  }
+  e->stats.sync_batches++;
+  return TRG_OK;
+}
+
+// ---- graph state helpers -----------------------------------------------------------------------
+void reset_graph_global(TrgEngine *e) {
+  e->nx.clear();
+  e->ny.clear();
+  e->nz.clear();
+  e->nstate.clear();
+  e->ncid.clear();
+  e->order_map.clear();
+  e->edges.reset(0);
+  e->node_id = 0;
+  e->kd.clear();
+  e->kd_valid = true;  // empty tree is trivially in sync
+  e->kd_insert_order.clear();
+  e->goal_node = -1;
+}
+
+void grid_rebuild(TrgEngine *e) {
+  const DevMap &m = e->gmap;
+  float x0 = m.bounds[0], y0 = m.bounds[1], x1 = m.bounds[2], y1 = m.bounds[3];
+  for (size_t i = 0; i < e->nx.size(); ++i) {
+    x0 = std::min(x0, e->nx[i]);
+    x1 = std::max(x1, e->nx[i]);
+    y0 = std::min(y0, e->ny[i]);
+    y1 = std::max(y1, e->ny[i]);
+  }
+  const float pad = e->prm.expand_dist * 2 + e->prm.robot_size;
+  float cell = e->prm.robot_size > 0 ? e->prm.robot_size : 0.3f;
+  while (((double)(x1 - x0 + 2 * pad) / cell + 5) * ((double)(y1 - y0 + 2 * pad) / cell + 5) > 128e6)
+    cell *= 2;
+  e->grid.reset(x0 - pad, y0 - pad, x1 + pad, y1 + pad, cell);
+  for (size_t i = 0; i < e->nx.size(); ++i) e->grid.insert(e->nx[i], e->ny[i]);
+}
+
+// bring the reference-shaped kd replica in sync with the node set (lazy: the replay only needs it
+// for ties and for step 3; queries need it for hit order)
+void kd_sync(TrgEngine *e) {
+  if (!e->kd_valid) {
+    e->kd.clear();
+    e->kd_valid = true;
+  }
+  while (e->kd.size() < e->kd_insert_order.size()) {
+    const int id = e->kd_insert_order[e->kd.size()];
+    e->kd.insert(e->nx[id], e->ny[id], id);
+  }
+}
+
+int add_node_host(TrgEngine *e, float x, float y, float z, int state) {
+  const int id = e->node_id;
+  e->nx.push_back(x);
+  e->ny.push_back(y);
+  e->nz.push_back(z);
+  e->nstate.push_back(state);
+  e->ncid.push_back((int)e->ncid.size());
+  e->order_map[id] = id;  // graph.nodes[node_id] = node (trg.cpp:248)
+  e->kd_insert_order.push_back(id);
+  e->grid.insert(x, y);
+  e->edges.grow_nodes(e->nx.size());
+  e->node_id++;
+  e->stats.created_nodes++;
+  return id;
+}
+
+// nearest existing node exactly as kd_nearest2 on node_tree would answer (trg.cpp:408-409)
+int nearest_node(TrgEngine *e, float qx, float qy) {
+  bool tie = false;
+  int s = e->grid.nearest(qx, qy, &tie);
+  if (tie) {
+    e->stats.nn_ties++;
+    kd_sync(e);
+    s = e->kd.nearest(qx, qy);
+  }
+  return s;
+}
+
+// ---- chunk pipeline ----------------------------------------------------------------------------
+TrgStatus ensure_chunks(TrgEngine *e) {
+  const int S = e->prm.sample_num;
+  if (e->chunk_S == S && e->chunks[0].done) return TRG_OK;
+  const size_t slots = (size_t)TrgEngine::CHUNK_MAX * std::max(S, 1);
+  for (Chunk &c : e->chunks) {
+    if (!c.done) {
+      HIPCHK(e, hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+      HIPCHK(e, hipEventCreate(&c.t0));
+      HIPCHK(e, hipEventCreate(&c.t1));
+      HIPCHK(e, hipEventCreate(&c.t2));
+    }
+    HIPCHK(e, alloc_pinned(c.node_xy, (size_t)TrgEngine::CHUNK_MAX * 2));
+    HIPCHK(e, alloc_pinned(c.node_xyz, (size_t)TrgEngine::CHUNK_MAX * 3));
+    HIPCHK(e, alloc_pinned(c.node_id, (size_t)TrgEngine::CHUNK_MAX));
+    HIPCHK(e, alloc_pinned(c.n_acc, (size_t)TrgEngine::CHUNK_MAX));
+    HIPCHK(e, alloc_pinned(c.n_draws, (size_t)TrgEngine::CHUNK_MAX));
+    HIPCHK(e, alloc_pinned(c.status, slots));
+    HIPCHK(e, alloc_pinned(c.n_pts, slots));
+    HIPCHK(e, alloc_pinned(c.sx, slots));
+    HIPCHK(e, alloc_pinned(c.sy, slots));
+    HIPCHK(e, alloc_pinned(c.sz, slots));
+    HIPCHK(e, alloc_pinned(c.weight, slots));
+    HIPCHK(e, alloc_pinned(c.dist, slots));
+  }
+  for (EdgeBatch &b : e->ebatches) {
+    if (!b.done) {
+      HIPCHK(e, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+      HIPCHK(e, hipEventCreate(&b.t0));
+      HIPCHK(e, hipEventCreate(&b.t1));
+    }
+    HIPCHK(e, alloc_pinned(b.p1, (size_t)TrgEngine::EBATCH_MAX * 3));
+    HIPCHK(e, alloc_pinned(b.p2, (size_t)TrgEngine::EBATCH_MAX * 3));
+    HIPCHK(e, alloc_pinned(b.weight, (size_t)TrgEngine::EBATCH_MAX));
+    HIPCHK(e, alloc_pinned(b.dist, (size_t)TrgEngine::EBATCH_MAX));
+    HIPCHK(e, alloc_pinned(b.status, (size_t)TrgEngine::EBATCH_MAX));
+    HIPCHK(e, alloc_pinned(b.n_pts, (size_t)TrgEngine::EBATCH_MAX));
+  }
+  e->chunk_S = S;
+  return TRG_OK;
+}
+
+TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
+  const int S = e->prm.sample_num;
+  c.first = first;
+  c.count = count;
+  for (int i = 0; i < count; ++i) {
+    const int id = e->queue[first + i];
+    c.node_xy.h[2 * i] = e->nx[id];
+    c.node_xy.h[2 * i + 1] = e->ny[id];
+    c.node_xyz.h[3 * i] = e->nx[id];
+    c.node_xyz.h[3 * i + 1] = e->ny[id];
+    c.node_xyz.h[3 * i + 2] = e->nz[id];
+    c.node_id.h[i] = id;
+  }
+  hipStream_t s = e->s_main;
+  const size_t slots = (size_t)count * S;
+  HIPCHK(e, hipMemcpyAsync(c.node_xy.d, c.node_xy.h, (size_t)count * 2 * sizeof(float),
+                           hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(c.node_xyz.d, c.node_xyz.h, (size_t)count * 3 * sizeof(float),
+                           hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(c.node_id.d, c.node_id.h, (size_t)count * sizeof(int),
+                           hipMemcpyHostToDevice, s));
+  const QueryParams q = qparams(e);
+  HIPCHK(e, hipEventRecord(c.t0, s));
+  launch_sample_nodes(e->gmap.view, q, e->d_cos, e->d_sin, e->sampler.table_bits, e->sampler.seed,
+                      e->epoch, c.node_xy.d, c.node_id.d, count, c.n_acc.d, c.n_draws.d, c.sx.d,
+                      c.sy.d, c.sz.d, e->d_ctr, s);
+  HIPCHK(e, hipEventRecord(c.t1, s));
+  launch_spec_edges(e->gmap.view, q, c.node_xyz.d, count, c.n_acc.d, c.sx.d, c.sy.d, c.sz.d,
+                    c.status.d, c.n_pts.d, c.weight.d, c.dist.d, e->d_ctr, s);
+  HIPCHK(e, hipEventRecord(c.t2, s));
+  HIPCHK(e, hipMemcpyAsync(c.n_acc.h, c.n_acc.d, (size_t)count * sizeof(int),
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.n_draws.h, c.n_draws.d, (size_t)count * sizeof(int),
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.sx.h, c.sx.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.sy.h, c.sy.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.sz.h, c.sz.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.status.h, c.status.d, slots * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.weight.h, c.weight.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.dist.h, c.dist.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipEventRecord(c.done, s));
+  c.in_flight = true;
+  e->stats.launches_sample_kernel++;
+  e->stats.launches_edge_kernel++;
+  return TRG_OK;
+}
+
+TrgStatus wait_chunk(TrgEngine *e, Chunk &c) {
+  if (!c.in_flight) return TRG_OK;
+  auto t0 = Clock::now();
+  HIPCHK(e, hipEventSynchronize(c.done));
+  e->stats.ms_wait_gpu += ms_since(t0);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c.t0, c.t1) == hipSuccess) e->stats.ms_sample_kernel += ms;
+  if (hipEventElapsedTime(&ms, c.t1, c.t2) == hipSuccess) e->stats.ms_edge_kernel += ms;
+  c.in_flight = false;
+  return TRG_OK;
+}
+
+TrgStatus collect_batch(TrgEngine *e, EdgeBatch &b) {
+  if (!b.in_flight) return TRG_OK;
+  auto t0 = Clock::now();
+  HIPCHK(e, hipEventSynchronize(b.done));
+  e->stats.ms_wait_gpu += ms_since(t0);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, b.t0, b.t1) == hipSuccess) e->stats.ms_edge_kernel += ms;
+  for (int i = 0; i < b.count; ++i) {
+    CallRec &c = e->calls[b.call_idx[i]];
+    c.dist = b.dist.h[i];
+    c.status = resolve_status(e, b.status.h[i], e->nz[c.n1], e->nz[c.n2], c.dist);
+    c.weight = (c.status == EDGE_OK) ? b.weight.h[i] : 0.0f;
+  }
+  b.in_flight = false;
+  b.count = 0;
+  return TRG_OK;
+}
+
+// ship the pending deferred wireEdge evaluations (node -> already existing node) to the GPU
+TrgStatus flush_pending(TrgEngine *e, bool all) {
+  size_t pos = 0;
+  while (e->pending_calls.size() - pos >= (all ? 1u : (size_t)TrgEngine::EBATCH_MAX)) {
+    // find a free batch buffer, collecting the oldest if none
+    EdgeBatch *b = nullptr;
+    for (EdgeBatch &cand : e->ebatches)
+      if (!cand.in_flight) {
+        b = &cand;
+        break;
+      }
+    if (!b) {
+      TrgStatus st = collect_batch(e, e->ebatches[0]);
+      if (st != TRG_OK) return st;
+      // rotate so that [0] is again the oldest
+      std::rotate(e->ebatches, e->ebatches + 1, e->ebatches + TrgEngine::NEBATCH);
+      b = &e->ebatches[TrgEngine::NEBATCH - 1];
+    }
+    const int cnt = (int)std::min<size_t>(TrgEngine::EBATCH_MAX, e->pending_calls.size() - pos);
+    b->call_idx.assign(e->pending_calls.begin() + pos, e->pending_calls.begin() + pos + cnt);
+    for (int i = 0; i < cnt; ++i) {
+      const CallRec &c = e->calls[b->call_idx[i]];
+      b->p1.h[3 * i] = e->nx[c.n1];
+      b->p1.h[3 * i + 1] = e->ny[c.n1];
+      b->p1.h[3 * i + 2] = e->nz[c.n1];
+      b->p2.h[3 * i] = e->nx[c.n2];
+      b->p2.h[3 * i + 1] = e->ny[c.n2];
+      b->p2.h[3 * i + 2] = e->nz[c.n2];
+    }
+    hipStream_t s = e->s_edge;
+    HIPCHK(e, hipMemcpyAsync(b->p1.d, b->p1.h, (size_t)cnt * 3 * sizeof(float),
+                             hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(b->p2.d, b->p2.h, (size_t)cnt * 3 * sizeof(float),
+                             hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipEventRecord(b->t0, s));
+    launch_edges(e->gmap.view, qparams(e), b->p1.d, b->p2.d, cnt, b->status.d, b->n_pts.d,
+                 b->weight.d, b->dist.d, e->d_ctr, s);
+    HIPCHK(e, hipEventRecord(b->t1, s));
+    HIPCHK(e, hipMemcpyAsync(b->status.h, b->status.d, (size_t)cnt * sizeof(int),
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemcpyAsync(b->weight.h, b->weight.d, (size_t)cnt * sizeof(float),
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemcpyAsync(b->dist.h, b->dist.d, (size_t)cnt * sizeof(float),
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipEventRecord(b->done, s));
+    b->in_flight = true;
+    b->count = cnt;
+    e->stats.launches_edge_kernel++;
+    e->stats.edge_evals_gpu += cnt;
+    pos += cnt;
+  }
+  e->pending_calls.erase(e->pending_calls.begin(), e->pending_calls.begin() + pos);
+  if (all) {
+    for (EdgeBatch &b : e->ebatches) {
+      TrgStatus st = collect_batch(e, b);
+      if (st != TRG_OK) return st;
+    }
+  }
+  return TRG_OK;
+}
+
+inline void emit_deferred(TrgEngine *e, int n1, int n2) {
+  if (n1 == n2) return;  // wireEdge returns at once (trg.cpp:255-257)
+  e->calls.push_back(CallRec{n1, n2, -1, 0.0f, 0.0f});
+  e->pending_calls.push_back((int)e->calls.size() - 1);
+  e->stats.edge_calls++;
+}
+
+// Apply the logged wireEdge() calls in program order: the dedupe of trg.cpp:255-267 and the two
+// push_backs of trg.cpp:365-368.  `from` = first call not yet applied.
+void apply_calls(TrgEngine *e, size_t from) {
+  e->edges.grow_nodes(e->nx.size());
+  for (size_t i = from; i < e->calls.size(); ++i) {
+    const CallRec &c = e->calls[i];
+    if (c.n1 == c.n2) continue;
+    if (e->edges.has(c.n1, c.n2) || e->edges.has(c.n2, c.n1)) continue;
+    if (c.status != EDGE_OK) continue;
+    e->edges.push(c.n1, c.n2, c.weight, c.dist);
+    e->edges.push(c.n2, c.n1, c.weight, c.dist);
+  }
+}
+
+// BFS expansion from the node `ref_id`, replaying trg.cpp:372-454 with GPU results.
+// `applied` is the index of the first call not yet folded into e->edges; step 3's validity test
+// needs edges of brand-new nodes only, which it derives locally.
+TrgStatus expand_bfs(TrgEngine *e, int ref_id) {
+  TrgStatus st = ensure_chunks(e);
+  if (st != TRG_OK) return st;
+  const int S = e->prm.sample_num;
+  const float r = e->prm.robot_size;
+  e->queue.clear();
+  e->queue.push_back(ref_id);
+  size_t head = 0;        // next queue position to replay
+  size_t submitted = 0;   // queue positions [0, submitted) have been shipped to the GPU
+  int next_buf = 0;       // chunk buffers are used round-robin, so completion order == queue order
+  std::deque<int> inflight;  // chunk buffer indices in submission order
+  std::vector<int> range_hits;
+  std::vector<float> s3_p1, s3_p2, s3_w, s3_d;
+  std::vector<int32_t> s3_st;
+  auto t_replay = Clock::now();
+  double waited0 = e->stats.ms_wait_gpu;
+
+  // Ship queue positions [submitted, submitted+cnt) in the next free buffer.  Buffers are used
+  // round-robin and consumed in the same order, so the oldest in-flight chunk is always next.
+  auto ship = [&](size_t cnt) -> TrgStatus {
+    Chunk &c = e->chunks[next_buf];
+    TrgStatus s2 = submit_chunk(e, c, (int)submitted, (int)cnt);
+    if (s2 != TRG_OK) return s2;
+    inflight.push_back(next_buf);
+    next_buf = (next_buf + 1) % TrgEngine::NCHUNK;
+    submitted += cnt;
+    return TRG_OK;
+  };
+
+  Chunk *cur = nullptr;
+  while (head < e->queue.size()) {
+    // keep the GPU fed while the replay works: full-size chunks as soon as enough nodes are queued,
+    // a small one only when the chunk being replayed is about to run dry
+    for (;;) {
+      const size_t avail = e->queue.size() - submitted;
+      const int busy = (int)inflight.size() + (cur ? 1 : 0);
+      if (avail == 0 || busy >= TrgEngine::NCHUNK) break;
+      const size_t left = cur ? (size_t)(cur->first + cur->count) - head : 0;
+      const bool starving = inflight.empty() && left <= 16;
+      if (avail < 512 && !starving) break;
+      st = ship(std::min<size_t>(avail, TrgEngine::CHUNK_MAX));
+      if (st != TRG_OK) return st;
+    }
+    if (!cur || (int)head >= cur->first + cur->count) {
+      cur = nullptr;
+      if (inflight.empty()) return e->fail(TRG_ERR_DEVICE, "replay starved (internal error)");
+      cur = &e->chunks[inflight.front()];
+      inflight.pop_front();
+      st = wait_chunk(e, *cur);
+      if (st != TRG_OK) return st;
+    }
+
+    const int qi = (int)head - cur->first;
+    const int node = e->queue[head];
+    head++;
+    e->stats.expanded_nodes++;
+    const int n_acc = cur->n_acc.h[qi];
+    e->stats.trials += cur->n_draws.h[qi];
+    e->stats.samples += n_acc;
+    e->stats.edge_evals_gpu += n_acc;
+
+    for (int j = 0; j < n_acc; ++j) {
+      const int slot = qi * S + j;
+      const float sx = cur->sx.h[slot], sy = cur->sy.h[slot];
+      // 1. nearest existing node (trg.cpp:408-417)
+      const int ex = nearest_node(e, sx, sy);
+      if (e->nstate[ex] == TRG_NODE_INVALID) continue;
+      if (norm2f(e->nx[ex] - sx, e->ny[ex] - sy) < r) {
+        emit_deferred(e, node, ex);
+        continue;
+      }
+      // 2. new node (trg.cpp:420-426); its parent edge was evaluated speculatively on the GPU
+      const int new_state = (ref_id == 0) ? TRG_NODE_VALID : TRG_NODE_FRONTIER;
+      const float sz = cur->sz.h[slot];
+      const int nn = add_node_host(e, sx, sy, sz, new_state);
+      const float dist = cur->dist.h[slot];
+      const int stt = resolve_status(e, cur->status.h[slot], e->nz[node], sz, dist);
+      const bool parent_ok = (stt == EDGE_OK);
+      e->calls.push_back(
+          CallRec{node, nn, stt, parent_ok ? cur->weight.h[slot] : 0.0f, dist});
+      e->stats.edge_calls++;
+      bool has_edge = parent_ok;
+
+      // 3. neighbour wiring (trg.cpp:429-444), only for configs like indoor.yaml
+      if (e->step3) {
+        kd_sync(e);
+        e->kd.range(e->nx[nn], e->ny[nn], e->prm.expand_dist, range_hits);
+        const size_t first_call = e->calls.size();
+        for (int other : range_hits) {
+          if (e->nstate[other] == TRG_NODE_INVALID) continue;
+          emit_deferred(e, nn, other);
+        }
+        if (!parent_ok && e->calls.size() > first_call) {
+          // the node's fate hangs on these edges: evaluate them now (synchronous round trip)
+          const size_t m = e->calls.size() - first_call;
+          s3_p1.resize(3 * m);
+          s3_p2.resize(3 * m);
+          s3_st.resize(m);
+          s3_w.resize(m);
+          s3_d.resize(m);
+          for (size_t k = 0; k < m; ++k) {
+            const CallRec &c = e->calls[first_call + k];
+            s3_p1[3 * k] = e->nx[c.n1];
+            s3_p1[3 * k + 1] = e->ny[c.n1];
+            s3_p1[3 * k + 2] = e->nz[c.n1];
+            s3_p2[3 * k] = e->nx[c.n2];
+            s3_p2[3 * k + 1] = e->ny[c.n2];
+            s3_p2[3 * k + 2] = e->nz[c.n2];
+          }
+          st = edges_sync(e, e->gmap, s3_p1.data(), s3_p2.data(), m, s3_st.data(), nullptr,
+                          s3_w.data(), s3_d.data(), true);
+          if (st != TRG_OK) return st;
+          for (size_t k = 0; k < m; ++k) {
+            CallRec &c = e->calls[first_call + k];
+            c.status = s3_st[k];
+            c.weight = s3_w[k];
+            c.dist = s3_d[k];
+            if (c.status == EDGE_OK) has_edge = true;
+          }
+          // they are resolved: take them off the pending list (they were appended last)
+          e->pending_calls.resize(e->pending_calls.size() - m);
+        }
+      }
+
+      // 4. (trg.cpp:447-451)
+      if (!has_edge) {
+        e->nstate[nn] = TRG_NODE_INVALID;
+        e->stats.invalid_nodes++;
+        continue;
+      }
+      e->queue.push_back(nn);
+    }
+    if ((int)e->pending_calls.size() >= TrgEngine::EBATCH_MAX) {
+      st = flush_pending(e, false);
+      if (st != TRG_OK) return st;
+    }
+  }
+  e->stats.ms_replay_host += ms_since(t_replay) - (e->stats.ms_wait_gpu - waited0);
+  return TRG_OK;
+}
+
+// ---- cleanGraph (trg.cpp:491-535) ---------------------------------------------------------------
+void snapshot_csr(const TrgEngine *e, Csr &out) {
+  const size_t V = e->nx.size();
+  out.clear();
+  out.xyz.resize(3 * V);
+  out.state.resize(V);
+  out.cid.resize(V);
+  out.rowptr.resize(V + 1);
+  out.rowptr[0] = 0;
+  for (size_t i = 0; i < V; ++i) {
+    out.xyz[3 * i] = e->nx[i];
+    out.xyz[3 * i + 1] = e->ny[i];
+    out.xyz[3 * i + 2] = e->nz[i];
+    out.state[i] = e->nstate[i];
+    out.cid[i] = e->ncid[i];
+    out.rowptr[i + 1] = out.rowptr[i] + (i < e->edges.deg.size() ? e->edges.deg[i] : 0);
+  }
+  const size_t E = out.rowptr[V];
+  out.col.resize(E);
+  out.w.resize(E);
+  out.dist.resize(E);
+  for (size_t i = 0; i < V; ++i) {
+    int k = out.rowptr[i];
+    if (i >= e->edges.head.size()) continue;
+    for (int ed = e->edges.head[i]; ed >= 0; ed = e->edges.next[ed]) {
+      out.col[k] = e->edges.dst[ed];
+      out.w[k] = e->edges.w[ed];
+      out.dist[k] = e->edges.dist[ed];
+      ++k;
+    }
+  }
+}
+
+void clean_graph(TrgEngine *e) {
+  const size_t V = e->nx.size();
+  std::vector<int> old2new(V, 0);  // old2new[] default-constructs 0 in the reference too
+  std::vector<int> keep_order;     // old ids in the order they receive new ids
+  std::vector<char> is_del(V, 0);
+  int new_id = 0;
+  // new ids follow the iteration order of the reference's unordered_map (trg.cpp:497-504)
+  std::unordered_map<int, int> new_nodes;
+  for (auto &kv : e->order_map) {
+    const int id = kv.first;
+    if (e->nstate[id] == TRG_NODE_INVALID || e->edges.deg[id] < 1) continue;
+    new_nodes[new_id] = new_id;
+    old2new[id] = new_id;
+    keep_order.push_back(id);
+    new_id++;
+    for (int ed = e->edges.head[id]; ed >= 0; ed = e->edges.next[ed]) {
+      const int d = e->edges.dst[ed];
+      if (e->nstate[d] == TRG_NODE_INVALID) is_del[d] = 1;
+    }
+  }
+  const int Vn = new_id;
+  std::vector<float> x2(Vn), y2(Vn), z2(Vn);
+  std::vector<int> st2(Vn), cid2(Vn);
+  EdgePool ep;
+  ep.reset(Vn);
+  for (int k = 0; k < Vn; ++k) {
+    const int old = keep_order[k];
+    x2[k] = e->nx[old];
+    y2[k] = e->ny[old];
+    z2[k] = e->nz[old];
+    st2[k] = e->nstate[old];
+    cid2[k] = e->ncid[old];
+    for (int ed = e->edges.head[old]; ed >= 0; ed = e->edges.next[ed]) {
+      const int d = e->edges.dst[ed];
+      if (is_del[d]) continue;
+      ep.push(k, old2new[d], e->edges.w[ed], e->edges.dist[ed]);
+    }
+  }
+  e->nx.swap(x2);
+  e->ny.swap(y2);
+  e->nz.swap(z2);
+  e->nstate.swap(st2);
+  e->ncid.swap(cid2);
+  e->edges = std::move(ep);
+  e->node_id = Vn;
+  // global_graph.nodes = new_nodes; then the node tree is refilled in that map's iteration order
+  e->order_map = new_nodes;
+  e->kd_insert_order.clear();
+  for (auto &kv : e->order_map) e->kd_insert_order.push_back(kv.first);
+  e->kd_valid = false;
+  grid_rebuild(e);
+}
+
+void read_counters(TrgEngine *e) {
+  DeviceCounters h{};
+  if (hipMemcpy(&h, e->d_ctr, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+    e->stats.bytes_sample_kernel = 12ull * h.sample_hits;
+    e->stats.bytes_edge_kernel = 12ull * h.edge_hits;
+    e->stats.nn_ties += h.nn_ties;
+  }
+}
+
+// ---- local graph (trg.cpp:211-231) ---------------------------------------------------------------
+TrgStatus set_local_graph(TrgEngine *e) {
+  e->local_nodes.clear();
+  e->lkd.clear();
+  const size_t V = e->nx.size();
+  if (V == 0) {
+    e->local_map.clear();
+    return TRG_OK;
+  }
+  // membership: any local-map point within robot_size/2 of the node (a disc-emptiness probe)
+  std::vector<float> xy(2 * V);
+  for (size_t i = 0; i < V; ++i) {
+    xy[2 * i] = e->nx[i];
+    xy[2 * i + 1] = e->ny[i];
+  }
+  std::vector<int32_t> n(V, 0);
+  if (e->lmap.valid) {
+    QueryParams q = qparams(e);
+    TrgParams save = e->prm;
+    e->prm.robot_size = (float)(save.robot_size * 0.5);
+    TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), V, nullptr, nullptr, n.data());
+    e->prm = save;
+    (void)q;
+    if (st != TRG_OK) return st;
+  }
+  e->local_map.clear();  // resetGraph("local"): clear() keeps the bucket array, as the reference's does
+  for (auto &kv : e->order_map) {
+    const int id = kv.first;
+    if (n[id] == 0) continue;
+    e->local_map[id] = id;
+    e->lkd.insert(e->nx[id], e->ny[id], id);
+  }
+  for (auto &kv : e->local_map) e->local_nodes.push_back(kv.first);
+  return TRG_OK;
+}
+
+}  // namespace
+
+// =================================== C ABI ======================================================
+extern "C" {
+
+TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out) {
+  if (!params || !out) return TRG_ERR_INVALID_ARG;
+  *out = nullptr;
+  TrgEngine *e = new TrgEngine();
+  e->prm = *params;
+  e->device = device;
+  *out = e;  // handed out even on failure so the caller can read last_error
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    return e->fail(TRG_ERR_DEVICE, "no HIP device visible: the TRG engine has no CPU fallback");
+  }
+  if (device < 0 || device >= ndev) return e->fail(TRG_ERR_INVALID_ARG, "bad device ordinal");
+  HIPCHK(e, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(e, hipGetDeviceProperties(&prop, device));
+  e->arch = prop.gcnArchName;
+  if (e->arch.rfind("gfx950", 0) != 0) {
+    return e->fail(TRG_ERR_DEVICE, "kernels are built for gfx950 only, device is " + e->arch);
+  }
+  HIPCHK(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+  HIPCHK(e, hipStreamCreateWithFlags(&e->s_edge, hipStreamNonBlocking));
+  HIPCHK(e, hipMalloc((void **)&e->d_ctr, sizeof(DeviceCounters)));
+  HIPCHK(e, hipMemset(e->d_ctr, 0, sizeof(DeviceCounters)));
+  HIPCHK(e, hipMalloc((void **)&e->d_bounds, 4 * sizeof(unsigned)));
+  // step 3 of expandGraph is compiled in or out by this fp comparison (trg.cpp:429)
+  e->step3 = (e->prm.expand_dist - e->prm.robot_size) < 0.25 * e->prm.expand_dist;
+  e->device_ok = true;
+  reset_graph_global(e);
+  return TRG_OK;
+}
+
+void trg_engine_destroy(TrgEngine *e) {
+  if (!e) return;
+  if (e->device_ok) {
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    free_map(e->gmap);
+    free_map(e->lmap);
+    for (Chunk &c : e->chunks) {
+      if (c.done) (void)hipEventDestroy(c.done);
+      if (c.t0) (void)hipEventDestroy(c.t0);
+      if (c.t1) (void)hipEventDestroy(c.t1);
+      if (c.t2) (void)hipEventDestroy(c.t2);
+      free_pinned(c.node_xy);
+      free_pinned(c.node_xyz);
+      free_pinned(c.node_id);
+      free_pinned(c.n_acc);
+      free_pinned(c.n_draws);
+      free_pinned(c.status);
+      free_pinned(c.n_pts);
+      free_pinned(c.sx);
+      free_pinned(c.sy);
+      free_pinned(c.sz);
+      free_pinned(c.weight);
+      free_pinned(c.dist);
+    }
+    for (EdgeBatch &b : e->ebatches) {
+      if (b.done) (void)hipEventDestroy(b.done);
+      if (b.t0) (void)hipEventDestroy(b.t0);
+      if (b.t1) (void)hipEventDestroy(b.t1);
+      free_pinned(b.p1);
+      free_pinned(b.p2);
+      free_pinned(b.weight);
+      free_pinned(b.dist);
+      free_pinned(b.status);
+      free_pinned(b.n_pts);
+    }
+    free_pinned(e->sy_in);
+    free_pinned(e->sy_in2);
+    free_pinned(e->sy_f0);
+    free_pinned(e->sy_f1);
+    free_pinned(e->sy_i0);
+    free_pinned(e->sy_i1);
+    free_pinned(e->sy_i2);
+    if (e->d_cos) (void)hipFree(e->d_cos);
+    if (e->d_sin) (void)hipFree(e->d_sin);
+    if (e->d_ctr) (void)hipFree(e->d_ctr);
+    if (e->d_bounds) (void)hipFree(e->d_bounds);
+    if (e->s_main) (void)hipStreamDestroy(e->s_main);
+    if (e->s_edge) (void)hipStreamDestroy(e->s_edge);
+  }
+  delete e;
+}
+
+const char *trg_engine_last_error(const TrgEngine *e) { return e ? e->err.c_str() : "null engine"; }
+const char *trg_engine_device_arch(const TrgEngine *e) { return e ? e->arch.c_str() : ""; }
+
+#define REQUIRE_DEVICE(e)                                                              \
+  do {                                                                                 \
+    if (!(e)) return TRG_ERR_INVALID_ARG;                                              \
+    if (!(e)->device_ok) return (e)->fail(TRG_ERR_DEVICE, "engine has no usable device"); \
+    if (hipSetDevice((e)->device) != hipSuccess)                                       \
+      return (e)->fail(TRG_ERR_DEVICE, "hipSetDevice failed");                         \
+  } while (0)
+
+TrgStatus trg_engine_set_global_map(TrgEngine *e, const float *xyz, size_t n, size_t stride) {
+  REQUIRE_DEVICE(e);
+  if ((n && !xyz) || stride < 3) return e->fail(TRG_ERR_INVALID_ARG, "bad map arguments");
+  auto t0 = Clock::now();
+  TrgStatus st = upload_and_build(e, e->gmap, xyz, n, stride);
+  e->stats.ms_set_map_total = ms_since(t0);
+  return st;
+}
+
+TrgStatus trg_engine_set_global_map_device(TrgEngine *e, const float *d_xyz, size_t n,
+                                           size_t stride) {
+  REQUIRE_DEVICE(e);
+  if ((n && !d_xyz) || stride < 3) return e->fail(TRG_ERR_INVALID_ARG, "bad map arguments");
+  if (n == 0) {
+    e->gmap.n = 0;
+    e->gmap.valid = false;
+    return TRG_OK;
+  }
+  return build_map(e, e->gmap, d_xyz, n, stride);
+}
+
+TrgStatus trg_engine_set_local_map(TrgEngine *e, const float start_xy[2], const float *xyz,
+                                   size_t n, size_t stride) {
+  REQUIRE_DEVICE(e);
+  if (!start_xy || (n && !xyz) || stride < 3) return e->fail(TRG_ERR_INVALID_ARG, "bad arguments");
+  e->local_root[0] = start_xy[0];
+  e->local_root[1] = start_xy[1];
+  TrgStatus st = upload_and_build(e, e->lmap, xyz, n, stride);
+  if (st != TRG_OK) return st;
+  return set_local_graph(e);
+}
+
+TrgStatus trg_engine_reset_map(TrgEngine *e, TrgKind kind) {
+  REQUIRE_DEVICE(e);
+  DevMap *m = pick_map(e, kind);
+  m->n = 0;
+  m->valid = false;
+  return TRG_OK;
+}
+
+TrgStatus trg_engine_reset_graph(TrgEngine *e, TrgKind kind) {
+  REQUIRE_DEVICE(e);
+  if (kind == TRG_KIND_LOCAL) {
+    e->local_nodes.clear();
+    e->local_map.clear();
+    e->lkd.clear();
+  } else {
+    reset_graph_global(e);
+    e->csr_global.clear();
+  }
+  return TRG_OK;
+}
+
+TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const TrgSampler *sampler) {
+  REQUIRE_DEVICE(e);
+  if (!start_xyz) return e->fail(TRG_ERR_INVALID_ARG, "null start");
+  if (!e->gmap.valid || e->gmap.n == 0) return e->fail(TRG_ERR_NO_MAP, "Map is empty");
+  auto t_total = Clock::now();
+  TrgStatus st = ensure_sampler(e, sampler);
+  if (st != TRG_OK) return st;
+  // per-build stats (map-index figures are kept)
+  {
+    TrgStats keep = e->stats;
+    e->stats = TrgStats();
+    e->stats.map_points = keep.map_points;
+    e->stats.ms_index_build = keep.ms_index_build;
+    e->stats.bytes_index_build = keep.bytes_index_build;
+    e->stats.ms_set_map_total = keep.ms_set_map_total;
+  }
+  HIPCHK(e, hipMemset(e->d_ctr, 0, sizeof(DeviceCounters)));
+  reset_graph_global(e);
+  e->epoch = 0;
+  e->calls.clear();
+  e->pending_calls.clear();
+  grid_rebuild(e);
+
+  // root seeding, trg.cpp:44-56
+  e->root_pos[0] = start_xyz[0];
+  e->root_pos[1] = start_xyz[1];
+  float rx = e->root_pos[0], ry = e->root_pos[1];
+  rx = rx + e->prm.expand_dist;
+  int cnt = 0;
+  for (;;) {
+    float xy[2] = {rx, ry};
+    int32_t flag = 1;
+    st = collision_sync(e, e->gmap, e->prm.collision_threshold, xy, 1, &flag, nullptr, nullptr);
+    if (st != TRG_OK) return st;
+    if (!flag) {
+      float z = 0;
+      int32_t found = 0;
+      st = nearest_z_sync(e, e->gmap, xy, 1, &z, &found);
+      if (st != TRG_OK) return st;
+      add_node_host(e, rx, ry, z, TRG_NODE_VALID);
+      break;
+    }
+    if (cnt > 100) return e->fail(TRG_ERR_NO_ROOT, "Failed to generate root node");
+    const float u0 = sampler_uniform(e, 2 * cnt), u1 = sampler_uniform(e, 2 * cnt + 1);
+    rx = rx + e->prm.expand_dist * u0;
+    ry = ry + e->prm.expand_dist * u1;
+    cnt++;
+  }
+
+  st = expand_bfs(e, e->node_id - 1);
+  if (st != TRG_OK) return st;
+  auto t_fin = Clock::now();
+  st = flush_pending(e, true);
+  if (st != TRG_OK) return st;
+  apply_calls(e, 0);
+  if (e->keep_preclean) snapshot_csr(e, e->csr_pre);
+  clean_graph(e);
+  snapshot_csr(e, e->csr_global);
+  e->stats.ms_finalize_host = ms_since(t_fin);
+  read_counters(e);
+  e->stats.ms_init_graph_total = ms_since(t_total);
+  return TRG_OK;
+}
+
+TrgStatus trg_engine_update_graph(TrgEngine *e) {
+  REQUIRE_DEVICE(e);
+  if (!e->gmap.valid) return e->fail(TRG_ERR_NO_MAP, "Map is empty");
+  TrgStatus st = ensure_sampler(e, nullptr);
+  if (st != TRG_OK) return st;
+  e->epoch++;
+  const size_t first_call = e->calls.size();
+  (void)first_call;
+  e->calls.clear();
+  e->pending_calls.clear();
+
+  // per local node: invalidate / keep frontier / revalidate (trg.cpp:464-481)
+  const size_t L = e->local_nodes.size();
+  std::vector<float> xy(2 * L);
+  for (size_t i = 0; i < L; ++i) {
+    xy[2 * i] = e->nx[e->local_nodes[i]];
+    xy[2 * i + 1] = e->ny[e->local_nodes[i]];
+  }
+  std::vector<int32_t> col(L, 0), fro(L, 0);
+  if (L) {
+    st = collision_sync(e, e->lmap, e->prm.update_collision_threshold, xy.data(), L, col.data(),
+                        nullptr, nullptr);
+    if (st != TRG_OK) return st;
+    st = trg_engine_is_frontier_batch(e, xy.data(), L, fro.data());
+    if (st != TRG_OK) return st;
+  }
+  std::vector<int> expand_queue;
+  for (size_t i = 0; i < L; ++i) {
+    const int id = e->local_nodes[i];
+    const float px = e->nx[id], py = e->ny[id];
+    if (norm2f(px - e->local_root[0], py - e->local_root[1]) > 2.0 * e->prm.expand_dist) {
+      if (col[i] || e->edges.deg[id] < 1) {
+        e->nstate[id] = TRG_NODE_INVALID;
+        continue;
+      }
+    }
+    if (fro[i] && e->nstate[id] == TRG_NODE_FRONTIER) {
+      e->nstate[id] = TRG_NODE_FRONTIER;
+      expand_queue.push_back(id);
+      continue;
+    }
+    expand_queue.push_back(id);
+    e->nstate[id] = TRG_NODE_VALID;
+  }
+  // isFrontier looked at the node set as it stood; expansions below mutate it, and the reference
+  // evaluates isFrontier lazily inside the same loop BEFORE any expansion, so this order is exact.
+  for (int id : expand_queue) {
+    const size_t from = e->calls.size();
+    st = expand_bfs(e, id);
+    if (st != TRG_OK) return st;
+    st = flush_pending(e, true);
+    if (st != TRG_OK) return st;
+    apply_calls(e, from);  // the next expandGraph call's dedupe must see these edges
+  }
+  if (e->keep_preclean) snapshot_csr(e, e->csr_pre);
+  clean_graph(e);
+  snapshot_csr(e, e->csr_global);
+  read_counters(e);
+  return set_local_graph(e);  // cleanGraph(true) -> setLocalGraph (trg.cpp:532-534)
+}
+
+TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out) {
+  if (!e || !out) return TRG_ERR_INVALID_ARG;
+  Csr *c = nullptr;
+  if (kind == TRG_KIND_GLOBAL) {
+    c = &e->csr_global;
+    if (c->rowptr.empty() || c->state.size() != e->nx.size()) snapshot_csr(e, *c);
+  } else if (kind == TRG_KIND_PRECLEAN) {
+    c = &e->csr_pre;
+  } else {
+    // local graph: the global rows of the local member nodes
+    c = &e->csr_local;
+    Csr full;
+    snapshot_csr(e, full);
+    c->clear();
+    c->rowptr.push_back(0);
+    for (int id : e->local_nodes) {
+      c->xyz.insert(c->xyz.end(), full.xyz.begin() + 3 * id, full.xyz.begin() + 3 * id + 3);
+      c->state.push_back(full.state[id]);
+      c->cid.push_back(id);  // for the local view: the node's global id
+      for (int k = full.rowptr[id]; k < full.rowptr[id + 1]; ++k) {
+        c->col.push_back(full.col[k]);
+        c->w.push_back(full.w[k]);
+        c->dist.push_back(full.dist[k]);
+      }
+      c->rowptr.push_back((int)c->col.size());
+    }
+  }
+  if (c->rowptr.empty()) c->rowptr.push_back(0);
+  out->num_nodes = (int32_t)c->state.size();
+  out->num_edges = (int32_t)c->col.size();
+  out->node_xyz = c->xyz.data();
+  out->node_state = c->state.data();
+  out->rowptr = c->rowptr.data();
+  out->col = c->col.data();
+  out->weight = c->w.data();
+  out->dist = c->dist.data();
+  out->creation_id = c->cid.data();
+  return TRG_OK;
+}
+
+// ---- JSON persistence (schema of trg.cpp:130-177) ---------------------------------------------
+TrgStatus trg_engine_save_json(TrgEngine *e, const char *path) {
+  if (!e || !path) return TRG_ERR_INVALID_ARG;
+  std::string p(path);
+  // save_path.extension().empty() -> append ".json" (trg.cpp:135-137)
+  {
+    size_t slash = p.find_last_of('/');
+    size_t dot = p.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) p += ".json";
+  }
+  std::ofstream f(p);
+  if (!f) return e->fail(TRG_ERR_IO, "cannot open " + p);
+  char buf[256];
+  f << "{\n    \"edges\": [";
+  // nodes/edges are listed in the node map's iteration order, like the reference
+  bool first = true;
+  for (auto &kv : e->order_map) {
+    const int id = kv.first;
+    for (int ed = e->edges.head[id]; ed >= 0; ed = e->edges.next[ed]) {
+      snprintf(buf, sizeof(buf),
+               "%s\n        {\n            \"dist\": %.9g,\n            \"source\": %d,\n"
+               "            \"target\": %d,\n            \"weight\": %.9g\n        }",
+               first ? "" : ",", (double)e->edges.dist[ed], id, e->edges.dst[ed],
+               (double)e->edges.w[ed]);
+      f << buf;
+      first = false;
+    }
+  }
+  f << (first ? "]" : "\n    ]") << ",\n    \"nodes\": [";
+  first = true;
+  for (auto &kv : e->order_map) {
+    const int id = kv.first;
+    snprintf(buf, sizeof(buf),
+             "%s\n        {\n            \"id\": %d,\n            \"pos\": [\n                %.9g,\n"
+             "                %.9g,\n                %.9g\n            ],\n            \"state\": %d\n"
+             "        }",
+             first ? "" : ",", id, (double)e->nx[id], (double)e->ny[id], (double)e->nz[id],
+             e->nstate[id]);
+    f << buf;
+    first = false;
+  }
+  f << (first ? "]" : "\n    ]") << "\n}";
+  f.close();
+  if (!f) return e->fail(TRG_ERR_IO, "write failed: " + p);
+  return TRG_OK;
+}
+
+namespace {
+// minimal JSON reader for the graph schema: arrays of flat objects with numeric members
+struct JsonCursor {
+  const std::string &s;
+  size_t i = 0;
+  explicit JsonCursor(const std::string &str) : s(str) {}
+  void ws() {
+    while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i;
+  }
+  bool eat(char c) {
+    ws();
+    if (i < s.size() && s[i] == c) {
+      ++i;
+      return true;
+    }
+    return false;
+  }
+  bool str(std::string &out) {
+    ws();
+    if (i >= s.size() || s[i] != '"') return false;
+    size_t j = s.find('"', i + 1);
+    if (j == std::string::npos) return false;
+    out = s.substr(i + 1, j - i - 1);
+    i = j + 1;
+    return true;
+  }
+  bool num(double &out) {
+    ws();
+    const char *b = s.c_str() + i;
+    char *end = nullptr;
+    out = strtod(b, &end);
+    if (end == b) return false;
+    i += (size_t)(end - b);
+    return true;
+  }
+};
+}  // namespace
+
+TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
+  REQUIRE_DEVICE(e);
+  if (!path) return TRG_ERR_INVALID_ARG;
+  std::ifstream f(path);
+  if (!f) return e->fail(TRG_ERR_IO, std::string("File not found: ") + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string txt = ss.str();
+  struct N {
+    int id;
+    float p[3];
+    int state;
+  };
+  struct Ed {
+    int s, t;
+    float w, d;
+  };
+  std::vector<N> nodes;
+  std::vector<Ed> eds;
+  JsonCursor c(txt);
+  if (!c.eat('{')) return e->fail(TRG_ERR_IO, "Failed to load graph: not a JSON object");
+  while (true) {
+    std::string key;
+    if (!c.str(key)) break;
+    if (!c.eat(':') || !c.eat('[')) return e->fail(TRG_ERR_IO, "Failed to load graph: bad array");
+    while (c.eat('{')) {
+      N n{0, {0, 0, 0}, 0};
+      Ed ed{0, 0, 0, 0};
+      while (true) {
+        std::string k;
+        if (!c.str(k)) break;
+        if (!c.eat(':')) return e->fail(TRG_ERR_IO, "Failed to load graph: bad member");
+        double v = 0;
+        if (k == "pos") {
+          if (!c.eat('[')) return e->fail(TRG_ERR_IO, "Failed to load graph: bad pos");
+          for (int q = 0; q < 3; ++q) {
+            if (!c.num(v)) return e->fail(TRG_ERR_IO, "Failed to load graph: bad pos");
+            n.p[q] = (float)v;
+            c.eat(',');
+          }
+          c.eat(']');
+        } else {
+          if (!c.num(v)) return e->fail(TRG_ERR_IO, "Failed to load graph: bad number");
+          if (k == "id") n.id = (int)v;
+          else if (k == "state") n.state = (int)v;
+          else if (k == "source") ed.s = (int)v;
+          else if (k == "target") ed.t = (int)v;
+          else if (k == "weight") ed.w = (float)v;
+          else if (k == "dist") ed.d = (float)v;
+        }
+        if (!c.eat(',')) break;
+      }
+      if (!c.eat('}')) return e->fail(TRG_ERR_IO, "Failed to load graph: unterminated object");
+      if (key == "nodes") nodes.push_back(n);
+      else if (key == "edges") eds.push_back(ed);
+      if (!c.eat(',')) break;
+    }
+    if (!c.eat(']')) return e->fail(TRG_ERR_IO, "Failed to load graph: unterminated array");
+    if (!c.eat(',')) break;
+  }
+  // loadPrebuiltGraph (trg.cpp:78-120): ids must be dense for the slot == id layout
+  int max_id = -1;
+  for (auto &n : nodes) max_id = std::max(max_id, n.id);
+  if (max_id + 1 != (int)nodes.size())
+    return e->fail(TRG_ERR_IO, "Failed to load graph: node ids are not dense 0..V-1");
+  reset_graph_global(e);
+  const size_t V = nodes.size();
+  e->nx.assign(V, 0);
+  e->ny.assign(V, 0);
+  e->nz.assign(V, 0);
+  e->nstate.assign(V, 0);
+  e->ncid.assign(V, 0);
+  e->edges.reset(V);
+  for (auto &n : nodes) {
+    e->nx[n.id] = n.p[0];
+    e->ny[n.id] = n.p[1];
+    e->nz[n.id] = n.p[2];
+    e->nstate[n.id] = n.state;
+    e->ncid[n.id] = n.id;
+    e->order_map[n.id] = n.id;          // global_graph.nodes[id] = node_ptr, file order
+    e->kd_insert_order.push_back(n.id);  // kd_insert2 in file order (trg.cpp:103)
+  }
+  e->node_id = (int)V;
+  for (auto &ed : eds) {
+    if (ed.s < 0 || ed.s >= (int)V) continue;
+    e->edges.push(ed.s, ed.t, ed.w, ed.d);
+  }
+  e->kd_valid = false;
+  grid_rebuild(e);
+  snapshot_csr(e, e->csr_global);
+  return TRG_OK;
+}
+
+// ---- planning (host A*, trg.cpp:537-565, 603-690) ------------------------------------------------
+TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goal_xyz[3],
+                          float *path_xyz, int32_t max_points, TrgPathInfo *info) {
+  if (!e || !start_xy || !goal_xyz || !info) return TRG_ERR_INVALID_ARG;
+  info->direct_dist = info->path_length = info->avg_risk = 0.0f;
+  info->num_points = 0;
+  const size_t V = e->nx.size();
+  if (V == 0) return e->fail(TRG_ERR_NO_GRAPH, "graph is empty");
+  kd_sync(e);
+
+  // setGoal
+  e->goal_pose2d[0] = goal_xyz[0];
+  e->goal_pose2d[1] = goal_xyz[1];
+  std::vector<int> hits;
+  e->kd.range(goal_xyz[0], goal_xyz[1], e->prm.robot_size, hits);
+  if (hits.empty()) {
+    float min_dist = std::numeric_limits<float>::max();
+    for (auto &kv : e->order_map) {
+      const int id = kv.first;
+      const float d = norm2f(e->nx[id] - goal_xyz[0], e->ny[id] - goal_xyz[1]);
+      if (d < min_dist) {
+        min_dist = d;
+        e->goal_node = id;
+      }
+    }
+    e->goal_known = false;
+  } else {
+    e->goal_node = hits[0];
+    e->goal_known = true;
+  }
+  const int goal = e->goal_node;
+  const int start = e->kd.nearest(start_xy[0], start_xy[1]);
+
+  struct Opt {
+    int id;
+    int parent;  // index into pool, -1 for the start
+    float f, g;
+  };
+  std::vector<Opt> pool;
+  auto cmp = [&pool](int a, int b) { return pool[a].f > pool[b].f; };
+  std::priority_queue<int, std::vector<int>, std::function<bool(int, int)>> open_list(cmp);
+  std::vector<int> open_check(V, -1), close_list(V, -1);
+
+  info->direct_dist = norm2f(e->nx[goal] - e->nx[start], e->ny[goal] - e->ny[start]);
+  double g_cost = 0.0;
+  double f_cost = g_cost + info->direct_dist;
+  pool.push_back(Opt{start, -1, (float)f_cost, (float)g_cost});
+  open_list.push(0);
+  open_check[start] = 0;
+
+  while (!open_list.empty()) {
+    const int oi = open_list.top();
+    open_list.pop();
+    const Opt cur = pool[oi];
+    open_check[cur.id] = -1;
+
+    if (cur.id == goal) {
+      std::vector<int> chain;
+      float sum_dist = 0.0, sum_weight = 0.0;
+      int node = oi;
+      while (node >= 0) {
+        const Opt &o = pool[node];
+        if (o.parent >= 0) {
+          const int pid = pool[o.parent].id;
+          for (int ed = e->edges.head[o.id]; ed >= 0; ed = e->edges.next[ed]) {
+            if (e->edges.dst[ed] == pid) {
+              sum_dist += e->edges.dist[ed];
+              sum_weight += e->edges.w[ed];
+              break;
+            }
+          }
+        }
+        chain.push_back(o.id);
+        node = o.parent;
+      }
+      const float avg_weight = sum_weight / chain.size();
+      std::reverse(chain.begin(), chain.end());
+      info->path_length = sum_dist;
+      info->avg_risk = avg_weight;
+      info->num_points = (int32_t)chain.size();
+      if (path_xyz) {
+        const int m = std::min<int>((int)chain.size(), max_points);
+        for (int i = 0; i < m; ++i) {
+          path_xyz[3 * i] = e->nx[chain[i]];
+          path_xyz[3 * i + 1] = e->ny[chain[i]];
+          path_xyz[3 * i + 2] = e->nz[chain[i]];
+        }
+      }
+      return TRG_OK;
+    }
+
+    close_list[cur.id] = oi;
+    for (int ed = e->edges.head[cur.id]; ed >= 0; ed = e->edges.next[ed]) {
+      const int dst = e->edges.dst[ed];
+      if (dst < 0 || dst >= (int)V) continue;
+      if (close_list[dst] != -1 || e->nstate[dst] == TRG_NODE_INVALID) continue;
+      const double next_g =
+          cur.g + (e->prm.safety_factor * e->edges.w[ed] + 1) * e->edges.dist[ed];
+      const double next_f = next_g + norm2f(e->nx[goal] - e->nx[dst], e->ny[goal] - e->ny[dst]);
+      pool.push_back(Opt{dst, oi, (float)next_f, (float)next_g});
+      const int ni = (int)pool.size() - 1;
+      if (open_check[dst] == -1) {
+        open_list.push(ni);
+        open_check[dst] = ni;
+      } else if (pool[ni].g < pool[open_check[dst]].g) {
+        open_list.push(ni);
+        open_check[dst] = ni;
+      }
+    }
+  }
+  return e->fail(TRG_ERR_NOT_FOUND, "no path");
+}
+
+int32_t trg_engine_refine_path(const float *in_xyz, int32_t n_in, float *out_xyz, int32_t max_out) {
+  if (!in_xyz || n_in <= 0) return 0;
+  // point_between == 1: p0,p1,p1,p2,p2,...  then a 3-tap mean, last point passed through
+  std::vector<float> dense;
+  for (int i = 0; i + 1 < n_in; ++i) {
+    dense.insert(dense.end(), in_xyz + 3 * i, in_xyz + 3 * i + 3);
+    dense.insert(dense.end(), in_xyz + 3 * i + 3, in_xyz + 3 * i + 6);
+  }
+  const int nd = (int)(dense.size() / 3);
+  int written = 0;
+  for (int i = 0; i < nd; ++i) {
+    float o[3];
+    if (i == nd - 1) {
+      o[0] = dense[3 * i];
+      o[1] = dense[3 * i + 1];
+      o[2] = dense[3 * i + 2];
+    } else {
+      float sum[3] = {0.0f, 0.0f, 0.0f};
+      int cnt = 0;
+      for (int j = i - 1; j < i + 2; ++j) {
+        if (j < 0 || j >= nd) continue;
+        for (int k = 0; k < 3; ++k) sum[k] += dense[3 * j + k];
+        cnt++;
+      }
+      for (int k = 0; k < 3; ++k) o[k] = sum[k] / cnt;
+    }
+    if (out_xyz && written < max_out) {
+      out_xyz[3 * written] = o[0];
+      out_xyz[3 * written + 1] = o[1];
+      out_xyz[3 * written + 2] = o[2];
+    }
+    written++;
+  }
+  return written;
+}
+
+// ---- probes --------------------------------------------------------------------------------------
+TrgStatus trg_engine_is_collision_batch(TrgEngine *e, TrgKind map, float threshold, const float *xy,
+                                        size_t m, int32_t *flag, int32_t *cnt, int32_t *n) {
+  REQUIRE_DEVICE(e);
+  if (m && !xy) return e->fail(TRG_ERR_INVALID_ARG, "null positions");
+  return collision_sync(e, *pick_map(e, map), threshold, xy, m, flag, cnt, n);
+}
+
+TrgStatus trg_engine_nearest_z_batch(TrgEngine *e, TrgKind map, const float *xy, size_t m, float *z) {
+  REQUIRE_DEVICE(e);
+  if (m && (!xy || !z)) return e->fail(TRG_ERR_INVALID_ARG, "null arguments");
+  return nearest_z_sync(e, *pick_map(e, map), xy, m, z, nullptr);
+}
+
+TrgStatus trg_engine_edge_risk_batch(TrgEngine *e, TrgKind map, const float *p1_xyz,
+                                     const float *p2_xyz, size_t m, int32_t *status, int32_t *n_pts,
+                                     float *weight, float *dist) {
+  REQUIRE_DEVICE(e);
+  if (m && (!p1_xyz || !p2_xyz)) return e->fail(TRG_ERR_INVALID_ARG, "null arguments");
+  return edges_sync(e, *pick_map(e, map), p1_xyz, p2_xyz, m, status, n_pts, weight, dist, true);
+}
+
+TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, int32_t *flag) {
+  REQUIRE_DEVICE(e);
+  if (m && (!xy || !flag)) return e->fail(TRG_ERR_INVALID_ARG, "null arguments");
+  // trg.cpp:780-803: check = pos + 2*robot_size*normalize(pos - local root); frontier iff no global
+  // node within robot_size of check AND no local-map point within robot_size/2 of it
+  kd_sync(e);
+  std::vector<float> chk(2 * m);
+  std::vector<int> hits;
+  std::vector<char> blocked(m, 0);
+  for (size_t i = 0; i < m; ++i) {
+    float dx = xy[2 * i] - e->local_root[0], dy = xy[2 * i + 1] - e->local_root[1];
+    const float sq = dx * dx + dy * dy;
+    if (sq > 0.0f) {
+      const float nrm = sqrtf(sq);
+      dx = dx / nrm;
+      dy = dy / nrm;
+    }
+    const float k = 2 * e->prm.robot_size;
+    chk[2 * i] = xy[2 * i] + k * dx;
+    chk[2 * i + 1] = xy[2 * i + 1] + k * dy;
+    e->kd.range(chk[2 * i], chk[2 * i + 1], e->prm.robot_size, hits);
+    blocked[i] = !hits.empty();
+  }
+  std::vector<int32_t> n(m, 0);
+  if (e->lmap.valid && m) {
+    TrgParams save = e->prm;
+    e->prm.robot_size = (float)(0.5 * save.robot_size);
+    TrgStatus st = collision_sync(e, e->lmap, 0.0f, chk.data(), m, nullptr, nullptr, n.data());
+    e->prm = save;
+    if (st != TRG_OK) return st;
+  }
+  for (size_t i = 0; i < m; ++i) flag[i] = (!blocked[i] && n[i] == 0) ? 1 : 0;
+  return TRG_OK;
+}
+
+TrgStatus trg_engine_get_stats(const TrgEngine *e, TrgStats *out) {
+  if (!e || !out) return TRG_ERR_INVALID_ARG;
+  *out = e->stats;
+  return TRG_OK;
+}
+
+TrgStatus trg_engine_get_sampler_table(TrgEngine *e, float *cos_out, float *sin_out) {
+  REQUIRE_DEVICE(e);
+  TrgStatus st = ensure_sampler(e, nullptr);
+  if (st != TRG_OK) return st;
+  if (cos_out) memcpy(cos_out, e->cos_t.data(), e->cos_t.size() * sizeof(float));
+  if (sin_out) memcpy(sin_out, e->sin_t.data(), e->sin_t.size() * sizeof(float));
+  return TRG_OK;
+}
+
+TrgStatus trg_engine_debug_map_index(TrgEngine *e, TrgKind map, float *x, float *y, float *z,
+                                     int32_t *perm, int32_t *grid_wh, float *origin_cell) {
+  REQUIRE_DEVICE(e);
+  DevMap &m = *pick_map(e, map);
+  if (!m.valid) return e->fail(TRG_ERR_NO_MAP, "no map");
+  if (x) HIPCHK(e, hipMemcpy(x, m.x, m.n * sizeof(float), hipMemcpyDeviceToHost));
+  if (y) HIPCHK(e, hipMemcpy(y, m.y, m.n * sizeof(float), hipMemcpyDeviceToHost));
+  if (z) HIPCHK(e, hipMemcpy(z, m.z, m.n * sizeof(float), hipMemcpyDeviceToHost));
+  if (perm) HIPCHK(e, hipMemcpy(perm, m.perm, m.n * sizeof(int), hipMemcpyDeviceToHost));
+  if (grid_wh) {
+    grid_wh[0] = m.view.W;
+    grid_wh[1] = m.view.H;
+  }
+  if (origin_cell) {
+    origin_cell[0] = m.view.x0;
+    origin_cell[1] = m.view.y0;
+    origin_cell[2] = m.g;
+  }
+  return TRG_OK;
+}
+
+}  // extern "C"

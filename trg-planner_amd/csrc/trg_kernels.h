@@ -1,0 +1,89 @@
+// trg_kernels.h -- host-visible launch interface of the gfx950 kernels (trg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trg {
+
+// Cell-sorted structure-of-arrays map index (replaces the reference's 2-D kd-tree of map points,
+// trg.cpp:185-188 / kdtree.c).  Cells are row-major (cy * W + cx); the points of the cells
+// [cx0..cx1] of one row are one contiguous, coalesced range of x[], y[], z[].
+struct MapView {
+  const float *x;
+  const float *y;
+  const float *z;
+  const int *perm;        // original index of each sorted point (nearest-neighbour tie-break)
+  const int *cell_start;  // W*H + 1 exclusive prefix of points per cell
+  float x0, y0;           // grid origin (min x, min y of the cloud)
+  float inv_g;            // 1 / cell size
+  int W, H;
+  int n;
+};
+
+struct QueryParams {
+  float robot_size;
+  float height_threshold;
+  float collision_threshold;
+  float expand_dist;
+  int sample_num;
+};
+
+// result codes of the position-only part of wireEdge (trg.cpp:269-363)
+enum : int {
+  EDGE_OK = 0,
+  EDGE_GATE = 1,
+  EDGE_SEG = 2,
+  EDGE_EMPTY = 3,
+  EDGE_FEW = 4,
+  EDGE_STATUS_MASK = 7,
+  EDGE_GATE_UNCERTAIN = 8,  // rational slope test too close to call: host decides with libm atan2f
+  EDGE_CLAMPED = 16,        // weight < 0.1 -> 0 (trg.cpp:361-363)
+};
+
+struct DeviceCounters {
+  unsigned long long sample_hits;  // map points inside sample-collision discs
+  unsigned long long edge_hits;    // map points inside segment discs + ellipse gathers
+  unsigned long long nn_ties;
+  unsigned long long overflow;     // disc queries that used the large-disc fallback
+};
+
+// ---- index build -------------------------------------------------------------------------------
+// bounds[4] = {min_x, min_y, max_x, max_y} as order-preserving uint32 keys; init with init_bounds
+void launch_init_bounds(unsigned *d_bounds, hipStream_t s);
+void launch_bounds(const float *d_xyz, size_t n, size_t stride, unsigned *d_bounds, hipStream_t s);
+void launch_cell_count(const float *d_xyz, size_t n, size_t stride, float x0, float y0, float inv_g,
+                       int W, int H, int *d_cell_of, int *d_rank, int *d_counts, hipStream_t s);
+// exclusive scan of counts[0..m) into out[0..m], out[m] = total; tmp needs ceil(m/1024)+1 ints
+void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, hipStream_t s);
+void launch_scatter(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
+                    const int *d_rank, const int *d_cell_start, float *x, float *y, float *z,
+                    int *perm, hipStream_t s);
+void launch_cell_sort(int ncell, const int *d_cell_start, float *x, float *y, float *z, int *perm,
+                      hipStream_t s);
+
+// ---- queries -----------------------------------------------------------------------------------
+void launch_probe_collision(const MapView &m, QueryParams p, float threshold, const float *d_xy,
+                            int count, int *flag, int *cnt, int *n, DeviceCounters *ctr,
+                            hipStream_t s);
+void launch_probe_nearest_z(const MapView &m, QueryParams p, const float *d_xy, int count, float *z,
+                            int *found, DeviceCounters *ctr, hipStream_t s);
+// p1/p2: count x 3 floats
+void launch_edges(const MapView &m, QueryParams p, const float *d_p1, const float *d_p2, int count,
+                  int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
+                  hipStream_t s);
+
+// Expansion of `count` queued nodes (trg.cpp:384-403 sampling + the elevation lookup :244-247):
+//   node_xy[count*2], node_id[count] (sampler key), outputs per node: n_acc, n_draws and
+//   per slot (node*S + j): sample x, y, z
+void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
+                         int table_bits, uint32_t seed, uint32_t epoch, const float *node_xy,
+                         const int *node_id, int count, int *n_acc, int *n_draws, float *sx,
+                         float *sy, float *sz, DeviceCounters *ctr, hipStream_t s);
+// Speculative parent edges node -> sample for every accepted sample of a chunk:
+//   node_xyz[count*3]; slot = node*S + j evaluated iff j < n_acc[node]
+void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
+                       const int *n_acc, const float *sx, const float *sy, const float *sz,
+                       int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
+                       hipStream_t s);
+
+}  // namespace trg

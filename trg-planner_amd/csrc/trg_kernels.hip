@@ -1,0 +1,1031 @@
+// trg_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the TRG construction hot path.
+//
+// What each kernel reproduces (reference = /root/reference/cpp/trg_planner/core/trg_planner):
+//   index build   <- TRG::setGlobalMap's kd_insert2 loop            src/graph/trg.cpp:185-188
+//   disc_query    <- kd_nearest_range2 + TRG::isCollision            src/kdtree/kdtree.c:270-301, trg.cpp:746-778
+//                    (+ the kd_nearest2 elevation lookup, trg.cpp:244-247, fused when asked)
+//   edge_eval     <- the position-only part of TRG::wireEdge          trg.cpp:269-363
+//   sample_nodes  <- the rejection sampling loop of TRG::expandGraph  trg.cpp:384-403
+//
+// Execution model: one 64-lane wavefront per query.  A query's candidate points are the points
+// of a few cell rows of the cell-sorted SoA map; each row segment is ONE contiguous range, so the
+// 64 lanes issue coalesced loads of x[], y[], z[].  Hits are compacted with wave ballot +
+// popcount prefix into a per-wave LDS tile, the median is a rank selection over that tile.
+// No MFMA: nothing here is a dense contraction (the only "matrix" is a 3x3 covariance).
+//
+// Floating point: compiled with -ffp-contract=off; every fp32 decision (inclusive radius test,
+// ellipse test, segment walk accumulation, division/sqrt) is evaluated with the same operations
+// in the same order as the reference's x86-64 (no FMA) build, so decisions are bit-identical.
+#include "trg_kernels.h"
+
+#include <float.h>
+#include <limits.h>
+
+namespace trg {
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int HCAP = 1024;  // hits kept in the per-wave LDS tile; larger discs use the fallback
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  return (1ull << lane_id()) - 1ull;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS traffic of one wave is in order; this only stops the compiler from moving accesses
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float v0, float inv_g, int ncell) {
+  float t = floorf((v - v0) * inv_g);
+  // clamp in float first: the int conversion of a huge value is undefined
+  t = fminf(fmaxf(t, 0.0f), (float)(ncell - 1));
+  return (int)t;
+}
+
+__device__ __forceinline__ unsigned float_key(float f) {
+  unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+  unsigned b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+
+struct CellRange {
+  int cx0, cx1, cy0, cy1;
+};
+__device__ __forceinline__ CellRange cells_for(const MapView &m, float qx, float qy, float r) {
+  // conservative: the exact fp32 test decides membership, this only bounds the candidates
+  float rp = r * 1.001f + 1e-6f;
+  CellRange c;
+  c.cx0 = cell_coord(qx - rp, m.x0, m.inv_g, m.W);
+  c.cx1 = cell_coord(qx + rp, m.x0, m.inv_g, m.W);
+  c.cy0 = cell_coord(qy - rp, m.y0, m.inv_g, m.H);
+  c.cy1 = cell_coord(qy + rp, m.y0, m.inv_g, m.H);
+  return c;
+}
+
+struct Disc {
+  int n;        // points with d2 <= r2
+  int cnt;      // of those, |z - z_med| > height_threshold
+  float nn_z;   // z of the nearest point (only when NN)
+  int nn_tie;   // another point had the same fp32 d2 as the nearest
+};
+
+// Large-disc fallback: k-th smallest z by radix selection over the candidates, re-read from the
+// (L2-resident) map; no LDS tile needed.  Correct for any density, only slower.
+__device__ float select_kth_global(const MapView &m, const CellRange &c, float qx, float qy,
+                                   float r2, int k) {
+  unsigned prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    unsigned cand = prefix | (1u << bit);
+    int below = 0;
+    for (int cy = c.cy0; cy <= c.cy1; ++cy) {
+      int s = m.cell_start[cy * m.W + c.cx0];
+      int e = m.cell_start[cy * m.W + c.cx1 + 1];
+      for (int base = s; base < e; base += WAVE) {
+        int i = base + lane_id();
+        if (i < e) {
+          float dx = m.x[i] - qx, dy = m.y[i] - qy;
+          float d2 = dx * dx + dy * dy;
+          if (d2 <= r2 && float_key(m.z[i]) < cand) below++;
+        }
+      }
+    }
+    below = wave_sum(below);
+    if (below <= k) prefix = cand;
+  }
+  return key_float(prefix);
+}
+
+// One wave: all map points within r of (qx, qy) in 2-D, inclusive fp32 test with the reference's
+// operation order (kdtree.c:277-281), then the isCollision statistics (trg.cpp:763-772).
+template <bool NN>
+__device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float h, float *zbuf,
+                           DeviceCounters *ctr) {
+  const int lane = lane_id();
+  const float r2 = r * r;
+  const CellRange c = cells_for(m, qx, qy, r);
+  int n = 0;
+  float best_d2 = FLT_MAX, best_z = 0.0f;
+  int best_perm = INT_MAX;
+  for (int cy = c.cy0; cy <= c.cy1; ++cy) {
+    const int s = m.cell_start[cy * m.W + c.cx0];
+    const int e = m.cell_start[cy * m.W + c.cx1 + 1];
+    for (int base = s; base < e; base += WAVE) {
+      const int i = base + lane;
+      bool hit = false;
+      float z = 0.0f, d2 = 0.0f;
+      if (i < e) {
+        const float dx = m.x[i] - qx;
+        const float dy = m.y[i] - qy;
+        z = m.z[i];
+        d2 = dx * dx + dy * dy;
+        hit = d2 <= r2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int pos = n + __popcll(mask & lanemask_lt());
+        if (pos < HCAP) zbuf[pos] = z;
+        if (NN) {
+          const int pm = m.perm[i];
+          if (d2 < best_d2 || (d2 == best_d2 && pm < best_perm)) {
+            best_d2 = d2;
+            best_z = z;
+            best_perm = pm;
+          }
+        }
+      }
+      n += __popcll(mask);
+    }
+  }
+  Disc out;
+  out.n = n;
+  out.cnt = 0;
+  out.nn_z = 0.0f;
+  out.nn_tie = 0;
+  if (n == 0) return out;
+
+  if (NN) {
+    // wave arg-min over (d2, perm); afterwards every lane holds the winner
+    float wd = best_d2, wz = best_z;
+    int wp = best_perm;
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      const float od = __shfl_xor(wd, msk);
+      const float oz = __shfl_xor(wz, msk);
+      const int op = __shfl_xor(wp, msk);
+      if (od < wd || (od == wd && op < wp)) {
+        wd = od;
+        wz = oz;
+        wp = op;
+      }
+    }
+    out.nn_z = wz;
+    // a lane whose own best ties the winner with a different point
+    out.nn_tie = __ballot(best_perm != INT_MAX && best_d2 == wd && best_perm != wp) != 0ull;
+  }
+
+  float zmed;
+  const int k = n / 2;  // pts[pts.size() / 2] after the ascending sort (trg.cpp:764)
+  if (n <= HCAP) {
+    wave_lds_sync();
+    float mine = 0.0f;
+    bool found = false;
+    for (int i = lane; i < n; i += WAVE) {
+      const float zi = zbuf[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const float zj = zbuf[j];
+        rank += (zj < zi) || (zj == zi && j < i);
+      }
+      if (rank == k) {
+        mine = zi;
+        found = true;
+      }
+    }
+    const unsigned long long who = __ballot(found);
+    zmed = __shfl(mine, __ffsll((long long)who) - 1);
+    int cnt = 0;
+    for (int i = lane; i < n; i += WAVE) cnt += fabsf(zbuf[i] - zmed) > h;
+    out.cnt = wave_sum(cnt);
+    wave_lds_sync();  // tile is reused by the next query of this wave
+  } else {
+    if (ctr && lane == 0) atomicAdd(&ctr->overflow, 1ull);
+    zmed = select_kth_global(m, c, qx, qy, r2, k);
+    int cnt = 0;
+    for (int cy = c.cy0; cy <= c.cy1; ++cy) {
+      const int s = m.cell_start[cy * m.W + c.cx0];
+      const int e = m.cell_start[cy * m.W + c.cx1 + 1];
+      for (int base = s; base < e; base += WAVE) {
+        const int i = base + lane;
+        if (i < e) {
+          const float dx = m.x[i] - qx, dy = m.y[i] - qy;
+          const float d2 = dx * dx + dy * dy;
+          if (d2 <= r2 && fabsf(m.z[i] - zmed) > h) cnt++;
+        }
+      }
+    }
+    out.cnt = wave_sum(cnt);
+  }
+  return out;
+}
+
+__device__ __forceinline__ bool disc_collides(const Disc &d, float threshold) {
+  if (d.n == 0) return true;                       // trg.cpp:749-752
+  const float ratio = (float)d.cnt / (float)d.n;   // trg.cpp:773
+  return ratio > threshold;
+}
+
+// Nearest map point in 2-D for an arbitrary position: grow a square window of cells until the
+// best candidate is provably the nearest (everything outside the window is farther than R).
+__device__ bool nearest_point(const MapView &m, float qx, float qy, float r0, float &z_out,
+                              int &tie_out) {
+  const int lane = lane_id();
+  float R = r0;
+  for (int iter = 0; iter < 40; ++iter) {
+    const CellRange c = cells_for(m, qx, qy, R);
+    float best_d2 = FLT_MAX, best_z = 0.0f;
+    int best_perm = INT_MAX;
+    for (int cy = c.cy0; cy <= c.cy1; ++cy) {
+      const int s = m.cell_start[cy * m.W + c.cx0];
+      const int e = m.cell_start[cy * m.W + c.cx1 + 1];
+      for (int i = s + lane; i < e; i += WAVE) {
+        const float dx = m.x[i] - qx, dy = m.y[i] - qy;
+        const float d2 = dx * dx + dy * dy;
+        const int pm = m.perm[i];
+        if (d2 < best_d2 || (d2 == best_d2 && pm < best_perm)) {
+          best_d2 = d2;
+          best_z = m.z[i];
+          best_perm = pm;
+        }
+      }
+    }
+    float wd = best_d2, wz = best_z;
+    int wp = best_perm;
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      const float od = __shfl_xor(wd, msk);
+      const float oz = __shfl_xor(wz, msk);
+      const int op = __shfl_xor(wp, msk);
+      if (od < wd || (od == wd && op < wp)) {
+        wd = od;
+        wz = oz;
+        wp = op;
+      }
+    }
+    const bool whole = c.cx0 == 0 && c.cy0 == 0 && c.cx1 == m.W - 1 && c.cy1 == m.H - 1;
+    if (wp != INT_MAX && (wd <= R * R || whole)) {
+      z_out = wz;
+      tie_out = __ballot(best_perm != INT_MAX && best_d2 == wd && best_perm != wp) != 0ull;
+      return true;
+    }
+    if (whole) return false;
+    R *= 2.0f;
+  }
+  return false;
+}
+
+// ---- 3x3 SVD (U only), fp32: the published two-sided Jacobi of Eigen 3.4's JacobiSVD, which is
+// what the reference calls at trg.cpp:339 (Eigen/src/SVD/JacobiSVD.h, Eigen/src/Jacobi/Jacobi.h).
+struct Rot {
+  float c, s;
+};
+__device__ __forceinline__ Rot rot_mul(Rot a, Rot b) {
+  Rot r;
+  r.c = a.c * b.c - a.s * b.s;
+  r.s = a.c * b.s + a.s * b.c;
+  return r;
+}
+__device__ __forceinline__ Rot rot_t(Rot a) {
+  Rot r;
+  r.c = a.c;
+  r.s = -a.s;
+  return r;
+}
+__device__ __forceinline__ void rows_rotate(float M[3][3], int p, int q, Rot j) {
+  if (j.c == 1.0f && j.s == 0.0f) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float xi = M[p][i], yi = M[q][i];
+    M[p][i] = j.c * xi + j.s * yi;
+    M[q][i] = -j.s * xi + j.c * yi;
+  }
+}
+__device__ __forceinline__ void cols_rotate(float M[3][3], int p, int q, Rot j) {
+  const Rot t = rot_t(j);
+  if (t.c == 1.0f && t.s == 0.0f) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float xi = M[i][p], yi = M[i][q];
+    M[i][p] = t.c * xi + t.s * yi;
+    M[i][q] = -t.s * xi + t.c * yi;
+  }
+}
+__device__ __forceinline__ void make_jacobi(float x, float y, float z, Rot &r) {
+  const float deno = 2.0f * fabsf(y);
+  if (deno < FLT_MIN) {
+    r.c = 1.0f;
+    r.s = 0.0f;
+    return;
+  }
+  const float tau = (x - z) / deno;
+  const float w = sqrtf(tau * tau + 1.0f);
+  float t;
+  if (tau > 0.0f) {
+    t = 1.0f / (tau + w);
+  } else {
+    t = 1.0f / (tau - w);
+  }
+  const float sign_t = t > 0.0f ? 1.0f : -1.0f;
+  const float n = 1.0f / sqrtf(t * t + 1.0f);
+  r.s = -sign_t * (y / fabsf(y)) * fabsf(t) * n;
+  r.c = n;
+}
+__device__ __forceinline__ void jacobi_2x2(float W[3][3], int p, int q, Rot &jl, Rot &jr) {
+  float m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+  Rot rot1;
+  const float t = m00 + m11;
+  const float d = m10 - m01;
+  if (fabsf(d) < FLT_MIN) {
+    rot1.s = 0.0f;
+    rot1.c = 1.0f;
+  } else {
+    const float u = t / d;
+    const float tmp = sqrtf(1.0f + u * u);
+    rot1.s = 1.0f / tmp;
+    rot1.c = u / tmp;
+  }
+  if (!(rot1.c == 1.0f && rot1.s == 0.0f)) {
+    const float a0 = m00, b0 = m10, a1 = m01, b1 = m11;
+    m00 = rot1.c * a0 + rot1.s * b0;
+    m10 = -rot1.s * a0 + rot1.c * b0;
+    m01 = rot1.c * a1 + rot1.s * b1;
+    m11 = -rot1.s * a1 + rot1.c * b1;
+  }
+  make_jacobi(m00, m01, m11, jr);
+  jl = rot_mul(rot1, rot_t(jr));
+}
+__device__ void svd_u3(const float A[3][3], float U[3][3]) {
+  float W[3][3];
+  float scale = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) scale = fmaxf(scale, fabsf(A[r][c]));
+  if (scale == 0.0f) scale = 1.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      W[r][c] = A[r][c] / scale;
+      U[r][c] = (r == c) ? 1.0f : 0.0f;
+    }
+  const float precision = 2.0f * FLT_EPSILON;
+  float max_diag = fmaxf(fabsf(W[0][0]), fmaxf(fabsf(W[1][1]), fabsf(W[2][2])));
+  bool finished = false;
+  for (int sweep = 0; sweep < 1000 && !finished; ++sweep) {
+    finished = true;
+#pragma unroll
+    for (int p = 1; p < 3; ++p) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q >= p) continue;
+        const float threshold = fmaxf(FLT_MIN, precision * max_diag);
+        if (fabsf(W[p][q]) > threshold || fabsf(W[q][p]) > threshold) {
+          finished = false;
+          Rot jl, jr;
+          jacobi_2x2(W, p, q, jl, jr);
+          rows_rotate(W, p, q, jl);
+          cols_rotate(U, p, q, rot_t(jl));
+          cols_rotate(W, p, q, jr);
+          max_diag = fmaxf(max_diag, fmaxf(fabsf(W[p][p]), fabsf(W[q][q])));
+        }
+      }
+    }
+  }
+  float sv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a = fabsf(W[i][i]);
+    sv[i] = a;
+    if (a != 0.0f) {
+      const float sgn = W[i][i] / a;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) U[r][i] *= sgn;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sv[i] *= scale;
+  // sort by decreasing singular value (selection, first maximum wins)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int pos = i;
+    float mx = sv[i];
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) {
+      if (k2 > i && sv[k2] > mx) {
+        mx = sv[k2];
+        pos = k2;
+      }
+    }
+    if (mx == 0.0f) break;
+    if (pos != i) {
+      const float ts = sv[i];
+      sv[i] = sv[pos];
+      sv[pos] = ts;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float tu = U[r][i];
+        U[r][i] = U[r][pos];
+        U[r][pos] = tu;
+      }
+    }
+  }
+}
+
+struct EdgeOut {
+  int status;
+  int n_pts;
+  float weight;
+  float dist;
+};
+
+// One wave: the position-only part of TRG::wireEdge (trg.cpp:269-363) for node1=(x1,y1,z1),
+// node2=(x2,y2,z2).
+__device__ EdgeOut edge_eval(const MapView &m, const QueryParams &p, float x1, float y1, float z1,
+                             float x2, float y2, float z2, float *zbuf, DeviceCounters *ctr) {
+  const int lane = lane_id();
+  EdgeOut o;
+  o.status = EDGE_OK;
+  o.n_pts = 0;
+  o.weight = 0.0f;
+  const float ex = x1 - x2, ey = y1 - y2;
+  const float dist = sqrtf(ex * ex + ey * ey);  // (node1.head(2) - node2.head(2)).norm()
+  o.dist = dist;
+
+  // slope gate, trg.cpp:269-274: atan2f(|dz|, dist) > atan2f(h, r).  atan2 is monotone in the
+  // ratio, so the exact rational comparison |dz| * r  vs  h * dist decides it whenever the two
+  // sides differ by more than 1e-4 relative (fp32 atan2f error is ~1e-7); the sliver in between
+  // is flagged and the host applies the reference's own libm comparison.
+  int uncertain = 0;
+  {
+    const double lhs = (double)fabsf(z1 - z2) * (double)p.robot_size;
+    const double rhs = (double)p.height_threshold * (double)dist;
+    if (lhs > rhs * (1.0 + 1e-4)) {
+      o.status = EDGE_GATE;
+      return o;
+    }
+    if (!(lhs < rhs * (1.0 - 1e-4))) uncertain = EDGE_GATE_UNCERTAIN;
+  }
+
+  // dir = (node2 - node1).normalized(); center = node1 + 0.5 * dist * dir  (trg.cpp:277-278)
+  const float dx = x2 - x1, dy = y2 - y1;
+  const float sq = dx * dx + dy * dy;
+  float dirx = dx, diry = dy;
+  if (sq > 0.0f) {
+    const float nrm = sqrtf(sq);
+    dirx = dx / nrm;
+    diry = dy / nrm;
+  }
+  const float half = 0.5f * dist;
+  const float cx = x1 + half * dirx;
+  const float cy = y1 + half * diry;
+
+  unsigned long long hits = 0;
+  // segment walk, trg.cpp:282-288 (float accumulation of i is part of the semantics)
+  const float ds = p.robot_size * 0.5f;
+  int guard = 0;
+  for (float i = 0; i < dist; i += ds) {
+    const float qx = x1 + i * dirx;
+    const float qy = y1 + i * diry;
+    const Disc d = disc_query<false>(m, qx, qy, p.robot_size, p.height_threshold, zbuf, ctr);
+    hits += (unsigned long long)d.n;
+    if (disc_collides(d, p.collision_threshold)) {
+      o.status = EDGE_SEG | uncertain;
+      if (ctr && lane == 0) atomicAdd(&ctr->edge_hits, hits);
+      return o;
+    }
+    if (++guard > 100000 || !(ds > 0.0f)) break;
+  }
+
+  // ellipse with foci at the two nodes, trg.cpp:291-297
+  const float c = 0.5f * dist;
+  const float b = p.robot_size;
+  float a = b;
+  if (c >= b) a = sqrtf(c * c + b * b);
+  const bool is_circle = (a == b);
+  const float r00 = dirx, r01 = -diry, r10 = diry, r11 = dirx;  // trg.cpp:302-303
+  const float a2 = a * a;
+  const float bb = b * b;
+  const float aabb = a * a * b * b;
+
+  // gather + rotate + filter (trg.cpp:304-325); moments in fp64, z shifted by z1 for conditioning
+  const CellRange cr = cells_for(m, cx, cy, a);
+  double s_x = 0, s_y = 0, s_z = 0, s_xx = 0, s_xy = 0, s_xz = 0, s_yy = 0, s_yz = 0, s_zz = 0;
+  int kept = 0, in_range = 0;
+  for (int cyi = cr.cy0; cyi <= cr.cy1; ++cyi) {
+    const int s = m.cell_start[cyi * m.W + cr.cx0];
+    const int e = m.cell_start[cyi * m.W + cr.cx1 + 1];
+    for (int i = s + lane; i < e; i += WAVE) {
+      const float px = m.x[i], py = m.y[i];
+      const float ddx = px - cx, ddy = py - cy;
+      const float d2 = ddx * ddx + ddy * ddy;
+      if (d2 <= a2) {
+        in_range++;
+        const float X = r00 * ddx + r01 * ddy;
+        const float Y = r10 * ddx + r11 * ddy;
+        bool keep = is_circle;
+        if (!is_circle) keep = (X * X) * bb + (Y * Y) * a2 < aabb;
+        if (keep) {
+          kept++;
+          const double xd = (double)X, yd = (double)Y, zd = (double)m.z[i] - (double)z1;
+          s_x += xd;
+          s_y += yd;
+          s_z += zd;
+          s_xx += xd * xd;
+          s_xy += xd * yd;
+          s_xz += xd * zd;
+          s_yy += yd * yd;
+          s_yz += yd * zd;
+          s_zz += zd * zd;
+        }
+      }
+    }
+  }
+  in_range = wave_sum(in_range);
+  kept = wave_sum(kept);
+  hits += (unsigned long long)in_range;
+  if (ctr && lane == 0) atomicAdd(&ctr->edge_hits, hits);
+  o.n_pts = kept;
+  if (in_range == 0) {
+    o.status = EDGE_EMPTY | uncertain;
+    return o;
+  }
+  if (kept < 3) {
+    o.status = EDGE_FEW | uncertain;
+    return o;
+  }
+  s_x = wave_sum(s_x);
+  s_y = wave_sum(s_y);
+  s_z = wave_sum(s_z);
+  s_xx = wave_sum(s_xx);
+  s_xy = wave_sum(s_xy);
+  s_xz = wave_sum(s_xz);
+  s_yy = wave_sum(s_yy);
+  s_yz = wave_sum(s_yz);
+  s_zz = wave_sum(s_zz);
+
+  // covariance = centred^T * centred / (n - 1)  (trg.cpp:337-338), fp64 then rounded once
+  const double n = (double)kept;
+  const double mx = s_x / n, my = s_y / n, mz = s_z / n;
+  const double inv = 1.0 / (double)(kept - 1);
+  float cov[3][3];
+  cov[0][0] = (float)((s_xx - n * mx * mx) * inv);
+  cov[0][1] = (float)((s_xy - n * mx * my) * inv);
+  cov[0][2] = (float)((s_xz - n * mx * mz) * inv);
+  cov[1][1] = (float)((s_yy - n * my * my) * inv);
+  cov[1][2] = (float)((s_yz - n * my * mz) * inv);
+  cov[2][2] = (float)((s_zz - n * mz * mz) * inv);
+  cov[1][0] = cov[0][1];
+  cov[2][0] = cov[0][2];
+  cov[2][1] = cov[1][2];
+
+  float U[3][3];
+  svd_u3(cov, U);
+  // eigenvectors = U.normalized()  (divides by the Frobenius norm, trg.cpp:340)
+  float fro = 0.0f;
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) fro += U[r][cc] * U[r][cc];
+  float e20 = U[2][0], e21 = U[2][1];
+  if (fro > 0.0f) {
+    const float nrm = sqrtf(fro);
+    e20 = e20 / nrm;
+    e21 = e21 / nrm;
+  }
+  float hor = e20, ver = e21;  // col(k).dot(-gravity), trg.cpp:347-354
+  if (hor < 0.0f) hor = -e20;
+  if (ver < 0.0f) ver = -e21;
+  const float ratio = 0.8f;
+  float w = ratio * hor + (1 - ratio) * ver;
+  int clamped = 0;
+  if ((double)w < 0.1) {
+    w = 0.0f;
+    clamped = EDGE_CLAMPED;
+  }
+  o.weight = w;
+  o.status = EDGE_OK | uncertain | clamped;
+  return o;
+}
+
+// ---- murmur-style counter hash shared with the oracle's sampler ------------------------------
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t sample_hash(uint32_t seed, uint32_t epoch, uint32_t id,
+                                                uint32_t trial) {
+  uint32_t h = fmix32(seed ^ 0x9E3779B9u);
+  h = fmix32(h + epoch * 0x9E3779B9u + 0x7F4A7C15u);
+  h = fmix32(h + id * 0x85EBCA6Bu + 0x165667B1u);
+  h = fmix32(h + trial * 0xC2B2AE35u + 0x27D4EB2Fu);
+  return h;
+}
+
+// ================================ kernels =======================================================
+
+__global__ void k_init_bounds(unsigned *b) {
+  if (threadIdx.x == 0) {
+    b[0] = 0xFFFFFFFFu;
+    b[1] = 0xFFFFFFFFu;
+    b[2] = 0u;
+    b[3] = 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bounds(const float *xyz, size_t n, size_t stride,
+                                                unsigned *b) {
+  unsigned mnx = 0xFFFFFFFFu, mny = 0xFFFFFFFFu, mxx = 0u, mxy = 0u;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned kx = float_key(xyz[i * stride]);
+    const unsigned ky = float_key(xyz[i * stride + 1]);
+    mnx = min(mnx, kx);
+    mxx = max(mxx, kx);
+    mny = min(mny, ky);
+    mxy = max(mxy, ky);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    mnx = min(mnx, (unsigned)__shfl_xor((int)mnx, m));
+    mny = min(mny, (unsigned)__shfl_xor((int)mny, m));
+    mxx = max(mxx, (unsigned)__shfl_xor((int)mxx, m));
+    mxy = max(mxy, (unsigned)__shfl_xor((int)mxy, m));
+  }
+  if (lane_id() == 0) {
+    atomicMin(&b[0], mnx);
+    atomicMin(&b[1], mny);
+    atomicMax(&b[2], mxx);
+    atomicMax(&b[3], mxy);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cell_count(const float *xyz, size_t n, size_t stride,
+                                                    float x0, float y0, float inv_g, int W, int H,
+                                                    int *cell_of, int *rank, int *counts) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cx = cell_coord(xyz[i * stride], x0, inv_g, W);
+    const int cy = cell_coord(xyz[i * stride + 1], y0, inv_g, H);
+    const int c = cy * W + cx;
+    cell_of[i] = c;
+    rank[i] = atomicAdd(&counts[c], 1);
+  }
+}
+
+constexpr int SCAN_TILE = 2048;  // 256 threads x 8 items
+
+__global__ __launch_bounds__(256) void k_scan_tiles(const int *in, int *out, int m, int *tile_sum) {
+  __shared__ int wave_tot[4];
+  const int t = threadIdx.x;
+  const int base = blockIdx.x * SCAN_TILE + t * 8;
+  int v[8];
+  int local = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = base + k;
+    v[k] = idx < m ? in[idx] : 0;
+    local += v[k];
+  }
+  // inclusive scan of `local` inside the wave
+  int inc = local;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const int up = __shfl_up(inc, d);
+    if (lane_id() >= d) inc += up;
+  }
+  const int w = t >> 6;
+  if (lane_id() == WAVE - 1) wave_tot[w] = inc;
+  __syncthreads();
+  int wave_off = 0;
+  for (int k = 0; k < w; ++k) wave_off += wave_tot[k];
+  int run = wave_off + inc - local;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = base + k;
+    if (idx < m) out[idx] = run;
+    run += v[k];
+  }
+  if (t == 255) tile_sum[blockIdx.x] = wave_off + inc;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_sums(int *tile_sum, int nt) {
+  // single block: exclusive scan of nt tile sums in place, total appended at [nt]
+  __shared__ int carry;
+  __shared__ int wave_tot[4];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nt; base += 256) {
+    const int idx = base + threadIdx.x;
+    const int v = idx < nt ? tile_sum[idx] : 0;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const int up = __shfl_up(inc, d);
+      if (lane_id() >= d) inc += up;
+    }
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == WAVE - 1) wave_tot[w] = inc;
+    __syncthreads();
+    int off = carry;
+    for (int k = 0; k < w; ++k) off += wave_tot[k];
+    if (idx < nt) tile_sum[idx] = off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tile_sum[nt] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(int *out, int m, const int *tile_sum, int nt) {
+  const int off = tile_sum[blockIdx.x];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = base + k;
+    if (idx < m) out[idx] += off;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[m] = tile_sum[nt];
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const float *xyz, size_t n, size_t stride,
+                                                 const int *cell_of, const int *rank,
+                                                 const int *cell_start, float *x, float *y, float *z,
+                                                 int *perm) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int dst = cell_start[cell_of[i]] + rank[i];
+    x[dst] = xyz[i * stride];
+    y[dst] = xyz[i * stride + 1];
+    z[dst] = xyz[i * stride + 2];
+    perm[dst] = (int)i;
+  }
+}
+
+// The atomic rank above is arrival order; sorting every cell by original index makes the index
+// (and therefore every fp64 accumulation order downstream) independent of scheduling.
+__global__ __launch_bounds__(256) void k_cell_sort(int ncell, const int *cell_start, float *x,
+                                                   float *y, float *z, int *perm) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int s = cell_start[c], e = cell_start[c + 1];
+  for (int i = s + 1; i < e; ++i) {
+    const int kp = perm[i];
+    const float kx = x[i], ky = y[i], kz = z[i];
+    int j = i - 1;
+    while (j >= s && perm[j] > kp) {
+      perm[j + 1] = perm[j];
+      x[j + 1] = x[j];
+      y[j + 1] = y[j];
+      z[j + 1] = z[j];
+      --j;
+    }
+    perm[j + 1] = kp;
+    x[j + 1] = kx;
+    y[j + 1] = ky;
+    z[j + 1] = kz;
+  }
+}
+
+constexpr int QW = 4;  // waves (= queries) per block in the probe / edge kernels
+
+__global__ __launch_bounds__(QW *WAVE) void k_probe_collision(MapView m, QueryParams p,
+                                                              float threshold, const float *xy,
+                                                              int count, int *flag, int *cnt,
+                                                              int *nout, DeviceCounters *ctr) {
+  __shared__ float ztile[QW][HCAP];
+  const int w = threadIdx.x >> 6;
+  const int q = blockIdx.x * QW + w;
+  if (q >= count) return;
+  const Disc d = disc_query<false>(m, xy[2 * q], xy[2 * q + 1], p.robot_size, p.height_threshold,
+                                   ztile[w], ctr);
+  if (lane_id() == 0) {
+    if (flag) flag[q] = disc_collides(d, threshold) ? 1 : 0;
+    if (cnt) cnt[q] = d.cnt;
+    if (nout) nout[q] = d.n;
+  }
+}
+
+__global__ __launch_bounds__(QW *WAVE) void k_probe_nearest_z(MapView m, QueryParams p,
+                                                              const float *xy, int count, float *z,
+                                                              int *found, DeviceCounters *ctr) {
+  const int w = threadIdx.x >> 6;
+  const int q = blockIdx.x * QW + w;
+  if (q >= count) return;
+  float zz = 0.0f;
+  int tie = 0;
+  const bool ok = nearest_point(m, xy[2 * q], xy[2 * q + 1], p.robot_size, zz, tie);
+  if (lane_id() == 0) {
+    z[q] = ok ? zz : 0.0f;
+    if (found) found[q] = ok ? 1 : 0;
+    if (tie && ctr) atomicAdd(&ctr->nn_ties, 1ull);
+  }
+}
+
+__global__ __launch_bounds__(QW *WAVE) void k_edges(MapView m, QueryParams p, const float *p1,
+                                                    const float *p2, int count, int *status,
+                                                    int *n_pts, float *weight, float *dist,
+                                                    DeviceCounters *ctr) {
+  __shared__ float ztile[QW][HCAP];
+  const int w = threadIdx.x >> 6;
+  const int q = blockIdx.x * QW + w;
+  if (q >= count) return;
+  const EdgeOut o = edge_eval(m, p, p1[3 * q], p1[3 * q + 1], p1[3 * q + 2], p2[3 * q],
+                              p2[3 * q + 1], p2[3 * q + 2], ztile[w], ctr);
+  if (lane_id() == 0) {
+    status[q] = o.status;
+    n_pts[q] = o.n_pts;
+    weight[q] = o.weight;
+    dist[q] = o.dist;
+  }
+}
+
+__global__ __launch_bounds__(QW *WAVE) void k_spec_edges(MapView m, QueryParams p,
+                                                         const float *node_xyz, int count,
+                                                         const int *n_acc, const float *sx,
+                                                         const float *sy, const float *sz,
+                                                         int *status, int *n_pts, float *weight,
+                                                         float *dist, DeviceCounters *ctr) {
+  __shared__ float ztile[QW][HCAP];
+  const int w = threadIdx.x >> 6;
+  const int slot = blockIdx.x * QW + w;
+  const int S = p.sample_num;
+  if (slot >= count * S) return;
+  const int node = slot / S;
+  const int j = slot - node * S;
+  if (j >= n_acc[node]) return;
+  const EdgeOut o = edge_eval(m, p, node_xyz[3 * node], node_xyz[3 * node + 1],
+                              node_xyz[3 * node + 2], sx[slot], sy[slot], sz[slot], ztile[w], ctr);
+  if (lane_id() == 0) {
+    status[slot] = o.status;
+    n_pts[slot] = o.n_pts;
+    weight[slot] = o.weight;
+    dist[slot] = o.dist;
+  }
+}
+
+constexpr int SW = 8;  // waves per block in the sampling kernel = trials evaluated per round
+
+// One block per queued node: the rejection-sampling loop of expandGraph (trg.cpp:384-403).
+// Each round evaluates SW consecutive draws concurrently (one wave per draw); acceptance is
+// then decided in draw order, so the result equals the sequential loop's.
+__global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParams p,
+                                                           const float *cos_t, const float *sin_t,
+                                                           int table_bits, uint32_t seed,
+                                                           uint32_t epoch, const float *node_xy,
+                                                           const int *node_id, int count,
+                                                           int *n_acc_out, int *n_draws_out,
+                                                           float *sx, float *sy, float *sz,
+                                                           DeviceCounters *ctr) {
+  __shared__ float ztile[SW][HCAP];
+  __shared__ int r_col[SW];
+  __shared__ float r_x[SW], r_y[SW], r_z[SW];
+  const int node = blockIdx.x;
+  if (node >= count) return;
+  const int w = threadIdx.x >> 6;
+  const int lane = lane_id();
+  const float px = node_xy[2 * node], py = node_xy[2 * node + 1];
+  const uint32_t id = (uint32_t)node_id[node];
+  const int S = p.sample_num;
+  const int max_trial_sample = 1000;
+  int n_acc = 0, rejects = 0, draws = 0;
+  unsigned long long hits = 0;
+  int ties = 0;
+  while (n_acc < S && rejects <= max_trial_sample) {
+    const uint32_t t = (uint32_t)(draws + w);
+    const uint32_t k = sample_hash(seed, epoch, id, t) >> (32 - table_bits);
+    const float qx = px + p.expand_dist * cos_t[k];
+    const float qy = py + p.expand_dist * sin_t[k];
+    const Disc d =
+        disc_query<true>(m, qx, qy, p.robot_size, p.height_threshold, ztile[w], ctr);
+    if (lane == 0) {
+      r_col[w] = disc_collides(d, p.collision_threshold) ? 1 : 0;
+      r_x[w] = qx;
+      r_y[w] = qy;
+      r_z[w] = d.nn_z;
+    }
+    hits += (unsigned long long)d.n;
+    __syncthreads();
+    // in-order acceptance; every thread runs the same scalar loop so control stays uniform
+    for (int i = 0; i < SW; ++i) {
+      if (n_acc >= S || rejects > max_trial_sample) break;
+      draws++;
+      if (r_col[i]) {
+        rejects++;
+      } else {
+        if (threadIdx.x == 0) {
+          const int slot = node * S + n_acc;
+          sx[slot] = r_x[i];
+          sy[slot] = r_y[i];
+          sz[slot] = r_z[i];
+        }
+        if (i == w && d.nn_tie) ties++;
+        n_acc++;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    n_acc_out[node] = n_acc;
+    n_draws_out[node] = draws;
+  }
+  if (ctr && lane == 0) {
+    atomicAdd(&ctr->sample_hits, hits);
+    if (ties) atomicAdd(&ctr->nn_ties, (unsigned long long)ties);
+  }
+}
+
+inline int blocks_for(size_t n, int per_block, int cap) {
+  size_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > (size_t)cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+// ================================ launchers =====================================================
+
+void launch_init_bounds(unsigned *d_bounds, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, d_bounds);
+}
+void launch_bounds(const float *d_xyz, size_t n, size_t stride, unsigned *d_bounds, hipStream_t s) {
+  hipLaunchKernelGGL(k_bounds, dim3(blocks_for(n, 256, 2048)), dim3(256), 0, s, d_xyz, n, stride,
+                     d_bounds);
+}
+void launch_cell_count(const float *d_xyz, size_t n, size_t stride, float x0, float y0, float inv_g,
+                       int W, int H, int *d_cell_of, int *d_rank, int *d_counts, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_count, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, d_xyz, n,
+                     stride, x0, y0, inv_g, W, H, d_cell_of, d_rank, d_counts);
+}
+void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, hipStream_t s) {
+  const int nt = (m + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(256), 0, s, d_counts, d_out, m, d_tmp);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(256), 0, s, d_tmp, nt);
+  hipLaunchKernelGGL(k_scan_add, dim3(nt), dim3(256), 0, s, d_out, m, d_tmp, nt);
+}
+void launch_scatter(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
+                    const int *d_rank, const int *d_cell_start, float *x, float *y, float *z,
+                    int *perm, hipStream_t s) {
+  hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, d_xyz, n, stride,
+                     d_cell_of, d_rank, d_cell_start, x, y, z, perm);
+}
+void launch_cell_sort(int ncell, const int *d_cell_start, float *x, float *y, float *z, int *perm,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_sort, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d_cell_start,
+                     x, y, z, perm);
+}
+
+void launch_probe_collision(const MapView &m, QueryParams p, float threshold, const float *d_xy,
+                            int count, int *flag, int *cnt, int *n, DeviceCounters *ctr,
+                            hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_probe_collision, dim3((count + QW - 1) / QW), dim3(QW * WAVE), 0, s, m, p,
+                     threshold, d_xy, count, flag, cnt, n, ctr);
+}
+void launch_probe_nearest_z(const MapView &m, QueryParams p, const float *d_xy, int count, float *z,
+                            int *found, DeviceCounters *ctr, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_probe_nearest_z, dim3((count + QW - 1) / QW), dim3(QW * WAVE), 0, s, m, p,
+                     d_xy, count, z, found, ctr);
+}
+void launch_edges(const MapView &m, QueryParams p, const float *d_p1, const float *d_p2, int count,
+                  int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
+                  hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_edges, dim3((count + QW - 1) / QW), dim3(QW * WAVE), 0, s, m, p, d_p1, d_p2,
+                     count, status, n_pts, weight, dist, ctr);
+}
+void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
+                         int table_bits, uint32_t seed, uint32_t epoch, const float *node_xy,
+                         const int *node_id, int count, int *n_acc, int *n_draws, float *sx,
+                         float *sy, float *sz, DeviceCounters *ctr, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_sample_nodes, dim3(count), dim3(SW * WAVE), 0, s, m, p, cos_t, sin_t,
+                     table_bits, seed, epoch, node_xy, node_id, count, n_acc, n_draws, sx, sy, sz,
+                     ctr);
+}
+void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
+                       const int *n_acc, const float *sx, const float *sy, const float *sz,
+                       int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
+                       hipStream_t s) {
+  if (count <= 0) return;
+  const int slots = count * p.sample_num;
+  hipLaunchKernelGGL(k_spec_edges, dim3((slots + QW - 1) / QW), dim3(QW * WAVE), 0, s, m, p,
+                     node_xyz, count, n_acc, sx, sy, sz, status, n_pts, weight, dist, ctr);
+}
+
+}  // namespace trg
