@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- TRG construction throughput on MI355X (BASELINE.json metric).
+
+A "step" is one full Traversal-Risk-Graph build over one synthetic terrain tile whose points are
+already resident in HBM: map index build (setGlobalMap) + initGraph (BFS expansion + cleanGraph)
++ CSR in pinned/host memory.  value = (nodes + directed edges after cleanGraph) built per second,
+summed over all ranks.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, every rank builds the graph of its own terrain tile (spatial-tile
+sharding, no data-path collective; weak scaling).  torch / RCCL are used for the barrier and the
+max-over-ranks reduction only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "trg-planner_amd"))
+
+WORKLOADS = {
+    # name: (nx, ny, sample_num, label)
+    "c3": (3200, 3125, 16, "C3: synthetic 10M-pt Perlin terrain, mountain.yaml, sampleNum(k)=16"),
+    "c2": (1000, 1000, 7, "C2: synthetic 1M-pt mountain, mountain.yaml (S=7)"),
+    "small": (400, 400, 16, "smoke-size 160k-pt terrain, mountain.yaml, S=16"),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MOUNTAIN = dict(expand_dist=0.6, robot_size=0.3, height_threshold=0.16, collision_threshold=0.1,
+                update_collision_threshold=0.5, safety_factor=3.0, goal_tolerance=0.8)
+
+
+def cpu_baseline(sample_num, seconds_hint=20.0):
+    """The CPU oracle (oracle/, a port of the reference algorithm; its spatial queries run through
+    the reference kdtree.c when oracle/_ref is present) timed on this box's host, one core, on a
+    bounded tile of the same terrain generator / parameters."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as oa
+    from trg_planner import synth
+    nx = ny = 700  # 490 k points, ~32 k nodes at S=16: about 10-20 s of single-core work
+    cloud = synth.mountain_cloud(nx, ny, seed=20250418)
+    used_ref = oa.use_reference_kd(True)
+    prm = dict(MOUNTAIN, sample_num=sample_num)
+    o = oa.Oracle(**prm)
+    o.set_sampler(7, 0, 16)
+    t0 = time.perf_counter()
+    o.set_global_map(cloud)
+    t1 = time.perf_counter()
+    ok = o.init_graph([nx * 0.05, ny * 0.05, 0.0])
+    t2 = time.perf_counter()
+    g = o.graph(0)
+    c = o.counters()
+    oa.use_reference_kd(False)
+    items = g.V + g.E
+    return {
+        "value": items / (t2 - t0), "unit": "nodes+edges/s", "cores": 1, "kind": "port",
+        "sample": (f"{nx}x{ny}={nx * ny} pt tile of the same generator/params (S={sample_num}), "
+                   f"V'={g.V} E'={g.E}, index {t1 - t0:.2f}s + initGraph {t2 - t1:.2f}s; "
+                   f"TRG logic = oracle/trg_oracle.cpp (port), kd-tree = "
+                   f"{'reference kdtree.c (oracle/_ref)' if used_ref else 'oracle/okd.c restatement'}"),
+        "ok": bool(ok), "us_per_expanded_node": 1e6 * (t2 - t1) / max(1, c["expanded"]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=20250418)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import trg_planner
+    from trg_planner import synth
+
+    nx, ny, S, label = WORKLOADS[args.workload]
+    # spatial tile of this rank: tiles sit side by side along x; same generator, seed + rank
+    origin = (rank * nx * 0.1, 0.0)
+    cloud = synth.mountain_cloud(nx, ny, seed=args.seed + rank, origin=origin)
+    d_cloud = torch.from_numpy(cloud).to(dev)  # inputs resident in HBM before the timed region
+    n_pts = cloud.shape[0]
+    start = [origin[0] + nx * 0.05, origin[1] + ny * 0.05, 0.0]
+    del cloud
+
+    eng = trg_planner.Engine(**dict(MOUNTAIN, sample_num=S), device=local_rank)
+    eng.set_sampler(7, 16)
+
+    def step():
+        eng.set_global_map_device(d_cloud.data_ptr(), n_pts, 3)
+        eng.init_graph(start)
+        return eng.graph_sizes("global")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    items = 0
+    acc = {}
+    for _ in range(args.steps):
+        V, E = step()
+        items += V + E
+        st = eng.stats()
+        for k, v in st.items():
+            acc[k] = acc.get(k, 0) + v
+    fence()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        it = torch.tensor([items], dtype=torch.float64, device=dev)
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        items = float(it.item())
+
+    if rank == 0:
+        st = eng.stats()
+        kernels = {
+            "k_edges": (acc["bytes_edge_kernel"], acc["ms_edge_kernel"], acc["launches_edge_kernel"]),
+            "k_spec_edges": (acc["bytes_spec_kernel"], acc["ms_spec_kernel"],
+                             acc["launches_spec_kernel"]),
+            "k_sample_nodes": (acc["bytes_sample_kernel"], acc["ms_sample_kernel"],
+                               acc["launches_sample_kernel"]),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][1])
+        b, ms, launches = kernels[dom]
+        achieved = (b / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        out = {
+            "metric": "TRG nodes+edges built/sec", "value": items / dt, "unit": "nodes+edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": label, "points_per_gpu": n_pts, "V_prime": V, "E_prime": E,
+                "sampler": "counter-based table, seed 7, 16 bits",
+                "sharding": "one terrain tile per rank, no collective" if world > 1 else "single tile",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "alg_bytes_per_launch": b / max(1, launches),
+                "avg_launch_ms": ms / max(1, launches), "launches": launches,
+            },
+            "breakdown_last_step": {
+                "ms_index_build_gpu": st["ms_index_build"], "ms_init_graph_total": st["ms_init_graph_total"],
+                "ms_replay_host": st["ms_replay_host"], "ms_finalize_host": st["ms_finalize_host"],
+                "ms_wait_gpu": st["ms_wait_gpu"], "ms_sample_kernel": st["ms_sample_kernel"],
+                "ms_spec_kernel": st["ms_spec_kernel"], "ms_edge_kernel": st["ms_edge_kernel"],
+                "expanded_nodes": st["expanded_nodes"], "samples": st["samples"],
+                "edge_evals_gpu": st["edge_evals_gpu"], "nn_ties": st["nn_ties"],
+                "gate_uncertain": st["gate_uncertain"],
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(S)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

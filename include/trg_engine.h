@@ -107,14 +107,17 @@ typedef struct TrgStats {
   uint64_t gate_uncertain;     /* slope gates decided by host libm atan2f */
   uint64_t sync_batches;       /* synchronous GPU round trips forced by the replay */
   /* bytes of map points inside query radii that the GPU kernels touched (12 B per hit) */
-  uint64_t bytes_sample_kernel;
-  uint64_t bytes_edge_kernel;
+  uint64_t bytes_sample_kernel;   /* k_sample_nodes */
+  uint64_t bytes_spec_kernel;     /* k_spec_edges (speculative parent edges) */
+  uint64_t bytes_edge_kernel;     /* k_edges (deferred wireEdge evaluations) */
   uint64_t bytes_index_build;
-  /* device time per kernel family, milliseconds, measured with hipEvents on the launch stream */
+  /* device time per kernel, milliseconds, measured with hipEvents on the launch stream */
   double ms_index_build;
   double ms_sample_kernel;
+  double ms_spec_kernel;
   double ms_edge_kernel;
   uint64_t launches_sample_kernel;
+  uint64_t launches_spec_kernel;
   uint64_t launches_edge_kernel;
   /* host wall time, milliseconds */
   double ms_set_map_total;

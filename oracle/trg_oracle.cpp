@@ -392,16 +392,16 @@ struct WireTrace {  // one record per wireEdge() call that got past the dedupe
 
 class Oracle {
  public:
-  explicit Oracle(const OParams &p) : param_(p) {
+  explicit Oracle(const OParams &p) : param_(p), kd_(g_kd) {
     for (OGraph *g : {&global_, &local_}) {
-      g->node_tree = g_kd.create();
-      g->map_tree = g_kd.create();
+      g->node_tree = kd_.create();
+      g->map_tree = kd_.create();
     }
   }
   ~Oracle() {
     for (OGraph *g : {&global_, &local_}) {
-      g_kd.free_(g->node_tree);
-      g_kd.free_(g->map_tree);
+      kd_.free_(g->node_tree);
+      kd_.free_(g->map_tree);
     }
   }
 
@@ -411,12 +411,12 @@ class Oracle {
   void resetGraph(int type) {
     OGraph &g = graph(type);
     g.nodes.clear();
-    g_kd.clear(g.node_tree);
+    kd_.clear(g.node_tree);
     g.node_id = 0;
   }
   void resetMap(int type) {
     OGraph &g = graph(type);
-    g_kd.clear(g.map_tree);
+    kd_.clear(g.map_tree);
     g.cloud.clear();
   }
 
@@ -430,7 +430,7 @@ class Oracle {
     }
     for (size_t i = 0; i < n; ++i) {
       Pt &pt = g.cloud[i];
-      g_kd.insert2(g.map_tree, pt.x, pt.y, &pt);
+      kd_.insert2(g.map_tree, pt.x, pt.y, &pt);
     }
   }
 
@@ -446,7 +446,7 @@ class Oracle {
     }
     for (size_t i = 0; i < n; ++i) {
       Pt &pt = g.cloud[i];
-      g_kd.insert2(g.map_tree, pt.x, pt.y, &pt);
+      kd_.insert2(g.map_tree, pt.x, pt.y, &pt);
     }
     setLocalGraph();
   }
@@ -455,15 +455,15 @@ class Oracle {
   void setLocalGraph() {
     resetGraph(1);
     for (auto &node : global_.nodes) {
-      void *res = g_kd.nearest_range2(local_.map_tree, node.second->pos_[0], node.second->pos_[1],
+      void *res = kd_.nearest_range2(local_.map_tree, node.second->pos_[0], node.second->pos_[1],
                                       param_.robot_size * 0.5);
-      if (g_kd.res_size(res) == 0) {
-        g_kd.res_free(res);
+      if (kd_.res_size(res) == 0) {
+        kd_.res_free(res);
         continue;
       }
       local_.nodes[node.first] = node.second;
-      g_kd.insert2(local_.node_tree, node.second->pos_[0], node.second->pos_[1], node.second);
-      g_kd.res_free(res);
+      kd_.insert2(local_.node_tree, node.second->pos_[0], node.second->pos_[1], node.second);
+      kd_.res_free(res);
     }
   }
 
@@ -471,22 +471,22 @@ class Oracle {
   bool isCollision(float px, float py, int type, float threshold, int *out_cnt = nullptr,
                    int *out_n = nullptr) {
     OGraph &g = graph(type);
-    void *res = g_kd.nearest_range2(g.map_tree, px, py, param_.robot_size);
+    void *res = kd_.nearest_range2(g.map_tree, px, py, param_.robot_size);
     cnt_.collision_queries++;
-    if (g_kd.res_size(res) == 0) {
-      g_kd.res_free(res);
+    if (kd_.res_size(res) == 0) {
+      kd_.res_free(res);
       if (out_cnt) *out_cnt = 0;
       if (out_n) *out_n = 0;
       return true;
     }
     std::vector<Pt *> pts;
     float z_med = 0.0;
-    while (!g_kd.res_end(res)) {
-      Pt *pt = reinterpret_cast<Pt *>(g_kd.res_item_data(res));
+    while (!kd_.res_end(res)) {
+      Pt *pt = reinterpret_cast<Pt *>(kd_.res_item_data(res));
       pts.push_back(pt);
-      g_kd.res_next(res);
+      kd_.res_next(res);
     }
-    g_kd.res_free(res);
+    kd_.res_free(res);
     cnt_.collision_hits += pts.size();
 
     std::sort(pts.begin(), pts.end(), [](Pt *a, Pt *b) { return a->z < b->z; });
@@ -512,14 +512,14 @@ class Oracle {
   // identical fp32 squared distance (the winner then depends on tree shape)
   float nearestZ(float px, float py, int type, bool *ok = nullptr) {
     OGraph &g = graph(type);
-    void *res = g_kd.nearest2(g.map_tree, px, py);
+    void *res = kd_.nearest2(g.map_tree, px, py);
     cnt_.nn_map_queries++;
     if (!res) {
       if (ok) *ok = false;
       return 0.0f;
     }
-    Pt *pt = reinterpret_cast<Pt *>(g_kd.res_item_data(res));
-    g_kd.res_free(res);
+    Pt *pt = reinterpret_cast<Pt *>(kd_.res_item_data(res));
+    kd_.res_free(res);
     if (ok) *ok = true;
     return pt->z;
   }
@@ -537,7 +537,7 @@ class Oracle {
     node->cid_ = next_cid_++;
     all_created_.push_back(node);
     g.nodes[node_id] = node;
-    g_kd.insert2(g.node_tree, px, py, node);
+    kd_.insert2(g.node_tree, px, py, node);
     g.node_id++;
     cnt_.created++;
     return true;
@@ -591,16 +591,16 @@ class Oracle {
     OGraph &g = graph(type);
     // R << dir.x, -dir.y, dir.y, dir.x   (trg.cpp:302-303)
     float r00 = dirx, r01 = -diry, r10 = diry, r11 = dirx;
-    void *res = g_kd.nearest_range2(g.map_tree, cx, cy, a);
+    void *res = kd_.nearest_range2(g.map_tree, cx, cy, a);
     cnt_.ellipse_queries++;
-    cnt_.ellipse_hits += g_kd.res_size(res);
-    if (g_kd.res_size(res) == 0) {
-      g_kd.res_free(res);
+    cnt_.ellipse_hits += kd_.res_size(res);
+    if (kd_.res_size(res) == 0) {
+      kd_.res_free(res);
       return 3;
     }
     std::vector<Pt> ell;
-    while (!g_kd.res_end(res)) {
-      Pt *pt = reinterpret_cast<Pt *>(g_kd.res_item_data(res));
+    while (!kd_.res_end(res)) {
+      Pt *pt = reinterpret_cast<Pt *>(kd_.res_item_data(res));
       float qx = pt->x - cx, qy = pt->y - cy;
       Pt p;
       p.x = r00 * qx + r01 * qy;
@@ -614,9 +614,9 @@ class Oracle {
           ell.push_back(p);
         }
       }
-      g_kd.res_next(res);
+      kd_.res_next(res);
     }
-    g_kd.res_free(res);
+    kd_.res_free(res);
     n_pts = (int)ell.size();
     if (ell.size() < 3) {
       return 4;
@@ -763,9 +763,9 @@ class Oracle {
       cnt_.samples += samples.size();
 
       for (auto &sample : samples) {
-        void *res = g_kd.nearest2(g.node_tree, sample.first, sample.second);
-        ONode *existing_node = reinterpret_cast<ONode *>(g_kd.res_item_data(res));
-        g_kd.res_free(res);
+        void *res = kd_.nearest2(g.node_tree, sample.first, sample.second);
+        ONode *existing_node = reinterpret_cast<ONode *>(kd_.res_item_data(res));
+        kd_.res_free(res);
         cnt_.nn_node_queries++;
         if (existing_node->state_ == ST_INVALID) {
           continue;
@@ -784,20 +784,20 @@ class Oracle {
         wireEdge(node, new_node, type);
 
         if (param_.expand_dist - param_.robot_size < 0.25 * param_.expand_dist) {
-          void *res2 = g_kd.nearest_range2(g.node_tree, new_node->pos_[0], new_node->pos_[1],
+          void *res2 = kd_.nearest_range2(g.node_tree, new_node->pos_[0], new_node->pos_[1],
                                            param_.expand_dist);
-          if (g_kd.res_size(res2) > 0) {
-            while (!g_kd.res_end(res2)) {
-              ONode *ex = reinterpret_cast<ONode *>(g_kd.res_item_data(res2));
+          if (kd_.res_size(res2) > 0) {
+            while (!kd_.res_end(res2)) {
+              ONode *ex = reinterpret_cast<ONode *>(kd_.res_item_data(res2));
               if (ex->state_ == ST_INVALID) {
-                g_kd.res_next(res2);
+                kd_.res_next(res2);
                 continue;
               }
               wireEdge(new_node, ex, type);
-              g_kd.res_next(res2);
+              kd_.res_next(res2);
             }
           }
-          g_kd.res_free(res2);
+          kd_.res_free(res2);
         }
 
         if (new_node->edges_.size() < 1) {
@@ -883,7 +883,7 @@ class Oracle {
     g.nodes = new_nodes;
     g.node_id = new_id;
     for (auto &node : g.nodes) {
-      g_kd.insert2(g.node_tree, node.second->pos_[0], node.second->pos_[1], node.second);
+      kd_.insert2(g.node_tree, node.second->pos_[0], node.second->pos_[1], node.second);
     }
     if (updateLocal) {
       setLocalGraph();
@@ -901,18 +901,18 @@ class Oracle {
     }
     float k = 2 * param_.robot_size;
     float chx = px + k * dx, chy = py + k * dy;
-    void *res2 = g_kd.nearest_range2(global_.node_tree, chx, chy, param_.robot_size);
-    if (g_kd.res_size(res2) > 0) {
-      g_kd.res_free(res2);
+    void *res2 = kd_.nearest_range2(global_.node_tree, chx, chy, param_.robot_size);
+    if (kd_.res_size(res2) > 0) {
+      kd_.res_free(res2);
       return false;
     }
-    g_kd.res_free(res2);
-    void *res1 = g_kd.nearest_range2(local_.map_tree, chx, chy, 0.5 * param_.robot_size);
-    if (g_kd.res_size(res1) == 0) {
-      g_kd.res_free(res1);
+    kd_.res_free(res2);
+    void *res1 = kd_.nearest_range2(local_.map_tree, chx, chy, 0.5 * param_.robot_size);
+    if (kd_.res_size(res1) == 0) {
+      kd_.res_free(res1);
       return true;
     }
-    g_kd.res_free(res1);
+    kd_.res_free(res1);
     return false;
   }
 
@@ -950,9 +950,9 @@ class Oracle {
     OGraph &g = global_;
     goal_pose2d_[0] = goal[0];
     goal_pose2d_[1] = goal[1];
-    void *res = g_kd.nearest_range2(g.node_tree, goal[0], goal[1], param_.robot_size);
-    if (g_kd.res_size(res) == 0) {
-      g_kd.res_free(res);
+    void *res = kd_.nearest_range2(g.node_tree, goal[0], goal[1], param_.robot_size);
+    if (kd_.res_size(res) == 0) {
+      kd_.res_free(res);
       float min_dist = std::numeric_limits<float>::max();
       for (auto &node : g.nodes) {
         float dist = norm2(node.second->pos_[0] - goal[0], node.second->pos_[1] - goal[1]);
@@ -963,8 +963,8 @@ class Oracle {
       }
       goal_known_ = false;
     } else {
-      goal_node_ = reinterpret_cast<ONode *>(g_kd.res_item_data(res));
-      g_kd.res_free(res);
+      goal_node_ = reinterpret_cast<ONode *>(kd_.res_item_data(res));
+      kd_.res_free(res);
       goal_known_ = true;
     }
   }
@@ -974,9 +974,9 @@ class Oracle {
                     float &direct_dist, float &path_length, float &avg_risk) {
     setGoal(goal);
     OGraph &g = global_;
-    void *res = g_kd.nearest2(g.node_tree, start2d[0], start2d[1]);
-    ONode *start_node = reinterpret_cast<ONode *>(g_kd.res_item_data(res));
-    g_kd.res_free(res);
+    void *res = kd_.nearest2(g.node_tree, start2d[0], start2d[1]);
+    ONode *start_node = reinterpret_cast<ONode *>(kd_.res_item_data(res));
+    kd_.res_free(res);
 
     std::priority_queue<OptimizeNode *, std::vector<OptimizeNode *>,
                         std::function<bool(OptimizeNode *, OptimizeNode *)>>
@@ -1138,6 +1138,7 @@ class Oracle {
   }
 
   OParams param_;
+  KdApi kd_;  // backend captured at construction (own restatement or reference kdtree.c)
   OSampler sampler_;
   OCounters cnt_;
   OGraph global_, local_;

@@ -744,7 +744,7 @@ TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
   HIPCHK(e, hipEventRecord(c.done, s));
   c.in_flight = true;
   e->stats.launches_sample_kernel++;
-  e->stats.launches_edge_kernel++;
+  e->stats.launches_spec_kernel++;
   return TRG_OK;
 }
 
@@ -755,7 +755,7 @@ TrgStatus wait_chunk(TrgEngine *e, Chunk &c) {
   e->stats.ms_wait_gpu += ms_since(t0);
   float ms = 0;
   if (hipEventElapsedTime(&ms, c.t0, c.t1) == hipSuccess) e->stats.ms_sample_kernel += ms;
-  if (hipEventElapsedTime(&ms, c.t1, c.t2) == hipSuccess) e->stats.ms_edge_kernel += ms;
+  if (hipEventElapsedTime(&ms, c.t1, c.t2) == hipSuccess) e->stats.ms_spec_kernel += ms;
   c.in_flight = false;
   return TRG_OK;
 }
@@ -1095,6 +1095,7 @@ void read_counters(TrgEngine *e) {
   if (hipMemcpy(&h, e->d_ctr, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
     e->stats.bytes_sample_kernel = 12ull * h.sample_hits;
     e->stats.bytes_edge_kernel = 12ull * h.edge_hits;
+    e->stats.bytes_spec_kernel = 12ull * h.spec_hits;
     e->stats.nn_ties += h.nn_ties;
   }
 }

@@ -42,7 +42,8 @@ enum : int {
 
 struct DeviceCounters {
   unsigned long long sample_hits;  // map points inside sample-collision discs
-  unsigned long long edge_hits;    // map points inside segment discs + ellipse gathers
+  unsigned long long edge_hits;    // map points inside segment discs + ellipse gathers (k_edges)
+  unsigned long long spec_hits;    // same, speculative parent edges (k_spec_edges)
   unsigned long long nn_ties;
   unsigned long long overflow;     // disc queries that used the large-disc fallback
 };

@@ -451,7 +451,8 @@ struct EdgeOut {
 // One wave: the position-only part of TRG::wireEdge (trg.cpp:269-363) for node1=(x1,y1,z1),
 // node2=(x2,y2,z2).
 __device__ EdgeOut edge_eval(const MapView &m, const QueryParams &p, float x1, float y1, float z1,
-                             float x2, float y2, float z2, float *zbuf, DeviceCounters *ctr) {
+                             float x2, float y2, float z2, float *zbuf, DeviceCounters *ctr,
+                             unsigned long long *hit_counter) {
   const int lane = lane_id();
   EdgeOut o;
   o.status = EDGE_OK;
@@ -500,7 +501,7 @@ __device__ EdgeOut edge_eval(const MapView &m, const QueryParams &p, float x1, f
     hits += (unsigned long long)d.n;
     if (disc_collides(d, p.collision_threshold)) {
       o.status = EDGE_SEG | uncertain;
-      if (ctr && lane == 0) atomicAdd(&ctr->edge_hits, hits);
+      if (hit_counter && lane == 0) atomicAdd(hit_counter, hits);
       return o;
     }
     if (++guard > 100000 || !(ds > 0.0f)) break;
@@ -553,7 +554,7 @@ __device__ EdgeOut edge_eval(const MapView &m, const QueryParams &p, float x1, f
   in_range = wave_sum(in_range);
   kept = wave_sum(kept);
   hits += (unsigned long long)in_range;
-  if (ctr && lane == 0) atomicAdd(&ctr->edge_hits, hits);
+  if (hit_counter && lane == 0) atomicAdd(hit_counter, hits);
   o.n_pts = kept;
   if (in_range == 0) {
     o.status = EDGE_EMPTY | uncertain;
@@ -844,7 +845,8 @@ __global__ __launch_bounds__(QW *WAVE) void k_edges(MapView m, QueryParams p, co
   const int q = blockIdx.x * QW + w;
   if (q >= count) return;
   const EdgeOut o = edge_eval(m, p, p1[3 * q], p1[3 * q + 1], p1[3 * q + 2], p2[3 * q],
-                              p2[3 * q + 1], p2[3 * q + 2], ztile[w], ctr);
+                              p2[3 * q + 1], p2[3 * q + 2], ztile[w], ctr,
+                              ctr ? &ctr->edge_hits : nullptr);
   if (lane_id() == 0) {
     status[q] = o.status;
     n_pts[q] = o.n_pts;
@@ -868,7 +870,8 @@ __global__ __launch_bounds__(QW *WAVE) void k_spec_edges(MapView m, QueryParams 
   const int j = slot - node * S;
   if (j >= n_acc[node]) return;
   const EdgeOut o = edge_eval(m, p, node_xyz[3 * node], node_xyz[3 * node + 1],
-                              node_xyz[3 * node + 2], sx[slot], sy[slot], sz[slot], ztile[w], ctr);
+                              node_xyz[3 * node + 2], sx[slot], sy[slot], sz[slot], ztile[w], ctr,
+                              ctr ? &ctr->spec_hits : nullptr);
   if (lane_id() == 0) {
     status[slot] = o.status;
     n_pts[slot] = o.n_pts;

@@ -57,9 +57,10 @@ class TrgStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "map_points", "expanded_nodes", "trials", "samples", "created_nodes", "invalid_nodes",
         "edge_calls", "edge_evals_gpu", "nn_ties", "gate_uncertain", "sync_batches",
-        "bytes_sample_kernel", "bytes_edge_kernel", "bytes_index_build")] + [
+        "bytes_sample_kernel", "bytes_spec_kernel", "bytes_edge_kernel", "bytes_index_build")] + [
         ("ms_index_build", C.c_double), ("ms_sample_kernel", C.c_double),
-        ("ms_edge_kernel", C.c_double), ("launches_sample_kernel", C.c_uint64),
+        ("ms_spec_kernel", C.c_double), ("ms_edge_kernel", C.c_double),
+        ("launches_sample_kernel", C.c_uint64), ("launches_spec_kernel", C.c_uint64),
         ("launches_edge_kernel", C.c_uint64), ("ms_set_map_total", C.c_double),
         ("ms_init_graph_total", C.c_double), ("ms_replay_host", C.c_double),
         ("ms_finalize_host", C.c_double), ("ms_wait_gpu", C.c_double)]
@@ -242,6 +243,12 @@ class Engine:
                         arr(v.node_state, V, np.int32), arr(v.rowptr, V + 1, np.int32),
                         arr(v.col, E, np.int32), arr(v.weight, E, np.float32),
                         arr(v.dist, E, np.float32), arr(v.creation_id, V, np.int32))
+
+    def graph_sizes(self, kind="global"):
+        """(num_nodes, num_edges) without copying the arrays."""
+        v = TrgCsrView()
+        self._chk(self.L.trg_engine_export_csr(self.h, _KINDS[kind], C.byref(v)))
+        return int(v.num_nodes), int(v.num_edges)
 
     def save_json(self, path):
         self._chk(self.L.trg_engine_save_json(self.h, str(path).encode()))
