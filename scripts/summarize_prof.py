@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense a scripts/profile_gpu.sh output directory into a markdown summary (kernel stats from
+--kernel-trace --stats, per-kernel FETCH_SIZE / WRITE_SIZE sums from the two --pmc passes)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    hits = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    for tok in ("trg::(anonymous namespace)::", "void "):
+        name = name.replace(tok, "")
+    return name.split("(")[0][:60]
+
+
+print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
+st = find("trace", "*kernel_stats.csv")
+if st:
+    print("## kernel-trace --stats (bench.py --steps 2 --warmup 1)\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % |")
+    print("|---|---|---|---|---|---|---|")
+    with open(st) as f:
+        for r in csv.DictReader(f):
+            print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
+                  f"{float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | "
+                  f"{float(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
+    print()
+for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    cc = find(sub, "*counter_collection.csv")
+    if not cc:
+        print(f"## {ctr}: no counter file\n")
+        continue
+    tot = defaultdict(float)
+    calls = defaultdict(int)
+    with open(cc) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != ctr:
+                continue
+            k = short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"])
+            calls[k] += 1
+    print(f"## --pmc {ctr} (bench.py --steps 1 --warmup 0); raw counter unit = KiB\n")
+    print("| kernel | dispatches | sum (raw) | sum MB (raw*1024/1e6) | per dispatch KB |")
+    print("|---|---|---|---|---|")
+    for k in sorted(tot, key=lambda k: -tot[k]):
+        print(f"| {k} | {calls[k]} | {tot[k]:.0f} | {tot[k] * 1024 / 1e6:.2f} | "
+              f"{tot[k] * 1024 / 1e3 / max(1, calls[k]):.1f} |")
+    print()

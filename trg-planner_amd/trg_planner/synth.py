@@ -97,6 +97,8 @@ def indoor_cloud(seed=1, size=(40.0, 30.0), spacing=0.1, n_boxes=12, wall_h=2.5,
         w, h = rng.uniform(1.0, 6.0), rng.uniform(0.3, 4.0)
         if rng.uniform() < 0.5:
             w, h = h, w
+        w = min(w, size[0] - 5.0)
+        h = min(h, size[1] - 5.0)
         x0 = rng.uniform(2.0, size[0] - 2.0 - w)
         y0 = rng.uniform(2.0, size[1] - 2.0 - h)
         boxes.append((x0, y0, x0 + w, y0 + h))
