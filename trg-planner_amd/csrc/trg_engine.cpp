@@ -124,17 +124,44 @@ struct Csr {
   }
 };
 
+template <typename T>
+struct View {  // host / device views into a chunk's packed blobs
+  T *h = nullptr;
+  T *d = nullptr;
+};
+
 struct Chunk {
   int first = 0, count = 0;  // queue positions [first, first+count)
   bool in_flight = false;
   hipEvent_t done = nullptr;
   hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;  // sample start / sample end / edges end
-  // inputs
-  PinnedBuf<float> node_xy, node_xyz;
-  PinnedBuf<int> node_id;
-  // outputs
-  PinnedBuf<int> n_acc, n_draws, status, n_pts;
-  PinnedBuf<float> sx, sy, sz, weight, dist;
+  // one packed input blob (H2D) and one packed output blob (D2H) per chunk: a single copy each way
+  PinnedBuf<uint32_t> in_blob, out_blob;
+  float *d_mid = nullptr;  // phase-1 edge records (device only)
+  size_t mid_cap = 0;
+  View<float> node_xy, node_xyz, sx, sy, sz, weight, dist;
+  View<int> node_id, n_acc, n_draws, status;
+  size_t in_words = 0, out_words = 0;
+  void carve(int cnt, int S) {
+    const size_t c = (size_t)cnt, cs = c * (size_t)S;
+    auto iv = [&](size_t off) { return View<int>{(int *)in_blob.h + off, (int *)in_blob.d + off}; };
+    auto fv = [&](size_t off) { return View<float>{(float *)in_blob.h + off, (float *)in_blob.d + off}; };
+    node_xy = fv(0);
+    node_xyz = fv(2 * c);
+    node_id = iv(5 * c);
+    in_words = 6 * c;
+    auto io = [&](size_t off) { return View<int>{(int *)out_blob.h + off, (int *)out_blob.d + off}; };
+    auto fo = [&](size_t off) { return View<float>{(float *)out_blob.h + off, (float *)out_blob.d + off}; };
+    n_acc = io(0);
+    n_draws = io(c);
+    sx = fo(2 * c);
+    sy = fo(2 * c + cs);
+    sz = fo(2 * c + 2 * cs);
+    status = io(2 * c + 3 * cs);
+    weight = fo(2 * c + 4 * cs);
+    dist = fo(2 * c + 5 * cs);
+    out_words = 2 * c + 6 * cs;
+  }
 };
 
 struct EdgeBatch {
@@ -143,7 +170,8 @@ struct EdgeBatch {
   hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
   std::vector<int> call_idx;  // which CallRec each row fills
   PinnedBuf<float> p1, p2, weight, dist;
-  PinnedBuf<int> status, n_pts;
+  PinnedBuf<int> status;
+  float *d_mid = nullptr;
 };
 
 }  // namespace
@@ -200,6 +228,7 @@ struct TrgEngine {
   // small synchronous scratch
   PinnedBuf<float> sy_in, sy_in2, sy_f0, sy_f1;
   PinnedBuf<int> sy_i0, sy_i1, sy_i2;
+  float *sy_mid = nullptr;
   size_t sy_cap = 0;
 
   Csr csr_global, csr_pre, csr_local;
@@ -457,6 +486,9 @@ TrgStatus ensure_sync_scratch(TrgEngine *e, size_t m) {
   HIPCHK(e, alloc_pinned(e->sy_i0, cap));
   HIPCHK(e, alloc_pinned(e->sy_i1, cap));
   HIPCHK(e, alloc_pinned(e->sy_i2, cap));
+  if (e->sy_mid) (void)hipFree(e->sy_mid);
+  e->sy_mid = nullptr;
+  HIPCHK(e, hipMalloc((void **)&e->sy_mid, edge_mid_floats(cap) * sizeof(float)));
   e->sy_cap = cap;
   return TRG_OK;
 }
@@ -556,8 +588,8 @@ TrgStatus edges_sync(TrgEngine *e, DevMap &m, const float *p1, const float *p2, 
                              e->s_main));
     HIPCHK(e, hipMemcpyAsync(e->sy_in2.d, e->sy_in2.h, m_ * 3 * sizeof(float),
                              hipMemcpyHostToDevice, e->s_main));
-    launch_edges(m.view, qparams(e), e->sy_in.d, e->sy_in2.d, (int)m_, e->sy_i0.d, e->sy_i1.d,
-                 e->sy_f0.d, e->sy_f1.d, e->d_ctr, e->s_main);
+    launch_edges(m.view, qparams(e), e->sy_in.d, e->sy_in2.d, (int)m_, e->sy_mid, e->sy_i0.d,
+                 e->sy_i1.d, e->sy_f0.d, e->sy_f1.d, e->d_ctr, e->s_main);
     HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
                              e->s_main));
     HIPCHK(e, hipMemcpyAsync(e->sy_i1.h, e->sy_i1.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
@@ -663,7 +695,8 @@ int nearest_node(TrgEngine *e, float qx, float qy) {
 TrgStatus ensure_chunks(TrgEngine *e) {
   const int S = e->prm.sample_num;
   if (e->chunk_S == S && e->chunks[0].done) return TRG_OK;
-  const size_t slots = (size_t)TrgEngine::CHUNK_MAX * std::max(S, 1);
+  const size_t cmax = TrgEngine::CHUNK_MAX;
+  const size_t slots = cmax * (size_t)std::max(S, 1);
   for (Chunk &c : e->chunks) {
     if (!c.done) {
       HIPCHK(e, hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
@@ -671,18 +704,14 @@ TrgStatus ensure_chunks(TrgEngine *e) {
       HIPCHK(e, hipEventCreate(&c.t1));
       HIPCHK(e, hipEventCreate(&c.t2));
     }
-    HIPCHK(e, alloc_pinned(c.node_xy, (size_t)TrgEngine::CHUNK_MAX * 2));
-    HIPCHK(e, alloc_pinned(c.node_xyz, (size_t)TrgEngine::CHUNK_MAX * 3));
-    HIPCHK(e, alloc_pinned(c.node_id, (size_t)TrgEngine::CHUNK_MAX));
-    HIPCHK(e, alloc_pinned(c.n_acc, (size_t)TrgEngine::CHUNK_MAX));
-    HIPCHK(e, alloc_pinned(c.n_draws, (size_t)TrgEngine::CHUNK_MAX));
-    HIPCHK(e, alloc_pinned(c.status, slots));
-    HIPCHK(e, alloc_pinned(c.n_pts, slots));
-    HIPCHK(e, alloc_pinned(c.sx, slots));
-    HIPCHK(e, alloc_pinned(c.sy, slots));
-    HIPCHK(e, alloc_pinned(c.sz, slots));
-    HIPCHK(e, alloc_pinned(c.weight, slots));
-    HIPCHK(e, alloc_pinned(c.dist, slots));
+    HIPCHK(e, alloc_pinned(c.in_blob, 6 * cmax));
+    HIPCHK(e, alloc_pinned(c.out_blob, 2 * cmax + 6 * slots));
+    if (c.mid_cap < slots) {
+      if (c.d_mid) (void)hipFree(c.d_mid);
+      c.d_mid = nullptr;
+      HIPCHK(e, hipMalloc((void **)&c.d_mid, edge_mid_floats(slots) * sizeof(float)));
+      c.mid_cap = slots;
+    }
   }
   for (EdgeBatch &b : e->ebatches) {
     if (!b.done) {
@@ -695,7 +724,9 @@ TrgStatus ensure_chunks(TrgEngine *e) {
     HIPCHK(e, alloc_pinned(b.weight, (size_t)TrgEngine::EBATCH_MAX));
     HIPCHK(e, alloc_pinned(b.dist, (size_t)TrgEngine::EBATCH_MAX));
     HIPCHK(e, alloc_pinned(b.status, (size_t)TrgEngine::EBATCH_MAX));
-    HIPCHK(e, alloc_pinned(b.n_pts, (size_t)TrgEngine::EBATCH_MAX));
+    if (!b.d_mid)
+      HIPCHK(e, hipMalloc((void **)&b.d_mid,
+                          edge_mid_floats(TrgEngine::EBATCH_MAX) * sizeof(float)));
   }
   e->chunk_S = S;
   return TRG_OK;
@@ -705,6 +736,7 @@ TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
   const int S = e->prm.sample_num;
   c.first = first;
   c.count = count;
+  c.carve(count, S);
   for (int i = 0; i < count; ++i) {
     const int id = e->queue[first + i];
     c.node_xy.h[2 * i] = e->nx[id];
@@ -715,12 +747,7 @@ TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
     c.node_id.h[i] = id;
   }
   hipStream_t s = e->s_main;
-  const size_t slots = (size_t)count * S;
-  HIPCHK(e, hipMemcpyAsync(c.node_xy.d, c.node_xy.h, (size_t)count * 2 * sizeof(float),
-                           hipMemcpyHostToDevice, s));
-  HIPCHK(e, hipMemcpyAsync(c.node_xyz.d, c.node_xyz.h, (size_t)count * 3 * sizeof(float),
-                           hipMemcpyHostToDevice, s));
-  HIPCHK(e, hipMemcpyAsync(c.node_id.d, c.node_id.h, (size_t)count * sizeof(int),
+  HIPCHK(e, hipMemcpyAsync(c.in_blob.d, c.in_blob.h, c.in_words * sizeof(uint32_t),
                            hipMemcpyHostToDevice, s));
   const QueryParams q = qparams(e);
   HIPCHK(e, hipEventRecord(c.t0, s));
@@ -729,18 +756,10 @@ TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
                       c.sy.d, c.sz.d, e->d_ctr, s);
   HIPCHK(e, hipEventRecord(c.t1, s));
   launch_spec_edges(e->gmap.view, q, c.node_xyz.d, count, c.n_acc.d, c.sx.d, c.sy.d, c.sz.d,
-                    c.status.d, c.n_pts.d, c.weight.d, c.dist.d, e->d_ctr, s);
+                    c.d_mid, c.status.d, nullptr, c.weight.d, c.dist.d, e->d_ctr, s);
   HIPCHK(e, hipEventRecord(c.t2, s));
-  HIPCHK(e, hipMemcpyAsync(c.n_acc.h, c.n_acc.d, (size_t)count * sizeof(int),
+  HIPCHK(e, hipMemcpyAsync(c.out_blob.h, c.out_blob.d, c.out_words * sizeof(uint32_t),
                            hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.n_draws.h, c.n_draws.d, (size_t)count * sizeof(int),
-                           hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.sx.h, c.sx.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.sy.h, c.sy.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.sz.h, c.sz.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.status.h, c.status.d, slots * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.weight.h, c.weight.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.dist.h, c.dist.d, slots * sizeof(float), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipEventRecord(c.done, s));
   c.in_flight = true;
   e->stats.launches_sample_kernel++;
@@ -813,7 +832,7 @@ TrgStatus flush_pending(TrgEngine *e, bool all) {
     HIPCHK(e, hipMemcpyAsync(b->p2.d, b->p2.h, (size_t)cnt * 3 * sizeof(float),
                              hipMemcpyHostToDevice, s));
     HIPCHK(e, hipEventRecord(b->t0, s));
-    launch_edges(e->gmap.view, qparams(e), b->p1.d, b->p2.d, cnt, b->status.d, b->n_pts.d,
+    launch_edges(e->gmap.view, qparams(e), b->p1.d, b->p2.d, cnt, b->d_mid, b->status.d, nullptr,
                  b->weight.d, b->dist.d, e->d_ctr, s);
     HIPCHK(e, hipEventRecord(b->t1, s));
     HIPCHK(e, hipMemcpyAsync(b->status.h, b->status.d, (size_t)cnt * sizeof(int),
@@ -1091,12 +1110,20 @@ void clean_graph(TrgEngine *e) {
 }
 
 void read_counters(TrgEngine *e) {
-  DeviceCounters h{};
-  if (hipMemcpy(&h, e->d_ctr, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-    e->stats.bytes_sample_kernel = 12ull * h.sample_hits;
-    e->stats.bytes_edge_kernel = 12ull * h.edge_hits;
-    e->stats.bytes_spec_kernel = 12ull * h.spec_hits;
-    e->stats.nn_ties += h.nn_ties;
+  std::vector<DeviceCounters> h(COUNTER_SHARDS);
+  if (hipMemcpy(h.data(), e->d_ctr, COUNTER_SHARDS * sizeof(DeviceCounters),
+                hipMemcpyDeviceToHost) == hipSuccess) {
+    unsigned long long sh = 0, eh = 0, ph = 0, ties = 0;
+    for (const DeviceCounters &c : h) {
+      sh += c.sample_hits;
+      eh += c.edge_hits;
+      ph += c.spec_hits;
+      ties += c.nn_ties;
+    }
+    e->stats.bytes_sample_kernel = 12ull * sh;
+    e->stats.bytes_edge_kernel = 12ull * eh;
+    e->stats.bytes_spec_kernel = 12ull * ph;
+    e->stats.nn_ties += ties;
   }
 }
 
@@ -1162,8 +1189,8 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
   }
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_edge, hipStreamNonBlocking));
-  HIPCHK(e, hipMalloc((void **)&e->d_ctr, sizeof(DeviceCounters)));
-  HIPCHK(e, hipMemset(e->d_ctr, 0, sizeof(DeviceCounters)));
+  HIPCHK(e, hipMalloc((void **)&e->d_ctr, COUNTER_SHARDS * sizeof(DeviceCounters)));
+  HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
   HIPCHK(e, hipMalloc((void **)&e->d_bounds, 4 * sizeof(unsigned)));
   // step 3 of expandGraph is compiled in or out by this fp comparison (trg.cpp:429)
   e->step3 = (e->prm.expand_dist - e->prm.robot_size) < 0.25 * e->prm.expand_dist;
@@ -1184,18 +1211,9 @@ void trg_engine_destroy(TrgEngine *e) {
       if (c.t0) (void)hipEventDestroy(c.t0);
       if (c.t1) (void)hipEventDestroy(c.t1);
       if (c.t2) (void)hipEventDestroy(c.t2);
-      free_pinned(c.node_xy);
-      free_pinned(c.node_xyz);
-      free_pinned(c.node_id);
-      free_pinned(c.n_acc);
-      free_pinned(c.n_draws);
-      free_pinned(c.status);
-      free_pinned(c.n_pts);
-      free_pinned(c.sx);
-      free_pinned(c.sy);
-      free_pinned(c.sz);
-      free_pinned(c.weight);
-      free_pinned(c.dist);
+      free_pinned(c.in_blob);
+      free_pinned(c.out_blob);
+      if (c.d_mid) (void)hipFree(c.d_mid);
     }
     for (EdgeBatch &b : e->ebatches) {
       if (b.done) (void)hipEventDestroy(b.done);
@@ -1206,8 +1224,9 @@ void trg_engine_destroy(TrgEngine *e) {
       free_pinned(b.weight);
       free_pinned(b.dist);
       free_pinned(b.status);
-      free_pinned(b.n_pts);
+      if (b.d_mid) (void)hipFree(b.d_mid);
     }
+    if (e->sy_mid) (void)hipFree(e->sy_mid);
     free_pinned(e->sy_in);
     free_pinned(e->sy_in2);
     free_pinned(e->sy_f0);
@@ -1305,7 +1324,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     e->stats.bytes_index_build = keep.bytes_index_build;
     e->stats.ms_set_map_total = keep.ms_set_map_total;
   }
-  HIPCHK(e, hipMemset(e->d_ctr, 0, sizeof(DeviceCounters)));
+  HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
   reset_graph_global(e);
   e->epoch = 0;
   e->calls.clear();

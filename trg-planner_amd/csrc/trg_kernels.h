@@ -40,12 +40,16 @@ enum : int {
   EDGE_CLAMPED = 16,        // weight < 0.1 -> 0 (trg.cpp:361-363)
 };
 
-struct DeviceCounters {
+// Instrumentation counters, sharded so that concurrent blocks do not serialise on one address:
+// shard = blockIdx.x % COUNTER_SHARDS, one 128-byte line per shard, summed by the host.
+constexpr int COUNTER_SHARDS = 64;
+struct alignas(128) DeviceCounters {
   unsigned long long sample_hits;  // map points inside sample-collision discs
   unsigned long long edge_hits;    // map points inside segment discs + ellipse gathers (k_edges)
   unsigned long long spec_hits;    // same, speculative parent edges (k_spec_edges)
   unsigned long long nn_ties;
   unsigned long long overflow;     // disc queries that used the large-disc fallback
+  unsigned long long pad[11];
 };
 
 // ---- index build -------------------------------------------------------------------------------
@@ -69,9 +73,11 @@ void launch_probe_collision(const MapView &m, QueryParams p, float threshold, co
 void launch_probe_nearest_z(const MapView &m, QueryParams p, const float *d_xy, int count, float *z,
                             int *found, DeviceCounters *ctr, hipStream_t s);
 // p1/p2: count x 3 floats
+// mid: device scratch of edge_mid_floats(count) floats (phase-1 records consumed by phase 2)
 void launch_edges(const MapView &m, QueryParams p, const float *d_p1, const float *d_p2, int count,
-                  int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
-                  hipStream_t s);
+                  float *mid, int *status, int *n_pts, float *weight, float *dist,
+                  DeviceCounters *ctr, hipStream_t s);
+size_t edge_mid_floats(size_t edges);
 
 // Expansion of `count` queued nodes (trg.cpp:384-403 sampling + the elevation lookup :244-247):
 //   node_xy[count*2], node_id[count] (sampler key), outputs per node: n_acc, n_draws and
@@ -84,7 +90,7 @@ void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, co
 //   node_xyz[count*3]; slot = node*S + j evaluated iff j < n_acc[node]
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
                        const int *n_acc, const float *sx, const float *sy, const float *sz,
-                       int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
-                       hipStream_t s);
+                       float *mid, int *status, int *n_pts, float *weight, float *dist,
+                       DeviceCounters *ctr, hipStream_t s);
 
 }  // namespace trg

@@ -4,7 +4,8 @@
 //   index build   <- TRG::setGlobalMap's kd_insert2 loop            src/graph/trg.cpp:185-188
 //   disc_query    <- kd_nearest_range2 + TRG::isCollision            src/kdtree/kdtree.c:270-301, trg.cpp:746-778
 //                    (+ the kd_nearest2 elevation lookup, trg.cpp:244-247, fused when asked)
-//   edge_eval     <- the position-only part of TRG::wireEdge          trg.cpp:269-363
+//   edge_gather   <- the position-only part of TRG::wireEdge          trg.cpp:269-363
+//   (+ k_edge_finish: covariance -> JacobiSVD -> weight, trg.cpp:339-363)
 //   sample_nodes  <- the rejection sampling loop of TRG::expandGraph  trg.cpp:384-403
 //
 // Execution model: one 64-lane wavefront per query.  A query's candidate points are the points
@@ -208,7 +209,7 @@ __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float 
     out.cnt = wave_sum(cnt);
     wave_lds_sync();  // tile is reused by the next query of this wave
   } else {
-    if (ctr && lane == 0) atomicAdd(&ctr->overflow, 1ull);
+    if (ctr && lane == 0) atomicAdd(&ctr[blockIdx.x % COUNTER_SHARDS].overflow, 1ull);
     zmed = select_kth_global(m, c, qx, qy, r2, k);
     int cnt = 0;
     for (int cy = c.cy0; cy <= c.cy1; ++cy) {
@@ -441,157 +442,11 @@ __device__ void svd_u3(const float A[3][3], float U[3][3]) {
   }
 }
 
-struct EdgeOut {
-  int status;
-  int n_pts;
-  float weight;
-  float dist;
-};
-
-// One wave: the position-only part of TRG::wireEdge (trg.cpp:269-363) for node1=(x1,y1,z1),
-// node2=(x2,y2,z2).
-__device__ EdgeOut edge_eval(const MapView &m, const QueryParams &p, float x1, float y1, float z1,
-                             float x2, float y2, float z2, float *zbuf, DeviceCounters *ctr,
-                             unsigned long long *hit_counter) {
-  const int lane = lane_id();
-  EdgeOut o;
-  o.status = EDGE_OK;
-  o.n_pts = 0;
-  o.weight = 0.0f;
-  const float ex = x1 - x2, ey = y1 - y2;
-  const float dist = sqrtf(ex * ex + ey * ey);  // (node1.head(2) - node2.head(2)).norm()
-  o.dist = dist;
-
-  // slope gate, trg.cpp:269-274: atan2f(|dz|, dist) > atan2f(h, r).  atan2 is monotone in the
-  // ratio, so the exact rational comparison |dz| * r  vs  h * dist decides it whenever the two
-  // sides differ by more than 1e-4 relative (fp32 atan2f error is ~1e-7); the sliver in between
-  // is flagged and the host applies the reference's own libm comparison.
-  int uncertain = 0;
-  {
-    const double lhs = (double)fabsf(z1 - z2) * (double)p.robot_size;
-    const double rhs = (double)p.height_threshold * (double)dist;
-    if (lhs > rhs * (1.0 + 1e-4)) {
-      o.status = EDGE_GATE;
-      return o;
-    }
-    if (!(lhs < rhs * (1.0 - 1e-4))) uncertain = EDGE_GATE_UNCERTAIN;
-  }
-
-  // dir = (node2 - node1).normalized(); center = node1 + 0.5 * dist * dir  (trg.cpp:277-278)
-  const float dx = x2 - x1, dy = y2 - y1;
-  const float sq = dx * dx + dy * dy;
-  float dirx = dx, diry = dy;
-  if (sq > 0.0f) {
-    const float nrm = sqrtf(sq);
-    dirx = dx / nrm;
-    diry = dy / nrm;
-  }
-  const float half = 0.5f * dist;
-  const float cx = x1 + half * dirx;
-  const float cy = y1 + half * diry;
-
-  unsigned long long hits = 0;
-  // segment walk, trg.cpp:282-288 (float accumulation of i is part of the semantics)
-  const float ds = p.robot_size * 0.5f;
-  int guard = 0;
-  for (float i = 0; i < dist; i += ds) {
-    const float qx = x1 + i * dirx;
-    const float qy = y1 + i * diry;
-    const Disc d = disc_query<false>(m, qx, qy, p.robot_size, p.height_threshold, zbuf, ctr);
-    hits += (unsigned long long)d.n;
-    if (disc_collides(d, p.collision_threshold)) {
-      o.status = EDGE_SEG | uncertain;
-      if (hit_counter && lane == 0) atomicAdd(hit_counter, hits);
-      return o;
-    }
-    if (++guard > 100000 || !(ds > 0.0f)) break;
-  }
-
-  // ellipse with foci at the two nodes, trg.cpp:291-297
-  const float c = 0.5f * dist;
-  const float b = p.robot_size;
-  float a = b;
-  if (c >= b) a = sqrtf(c * c + b * b);
-  const bool is_circle = (a == b);
-  const float r00 = dirx, r01 = -diry, r10 = diry, r11 = dirx;  // trg.cpp:302-303
-  const float a2 = a * a;
-  const float bb = b * b;
-  const float aabb = a * a * b * b;
-
-  // gather + rotate + filter (trg.cpp:304-325); moments in fp64, z shifted by z1 for conditioning
-  const CellRange cr = cells_for(m, cx, cy, a);
-  double s_x = 0, s_y = 0, s_z = 0, s_xx = 0, s_xy = 0, s_xz = 0, s_yy = 0, s_yz = 0, s_zz = 0;
-  int kept = 0, in_range = 0;
-  for (int cyi = cr.cy0; cyi <= cr.cy1; ++cyi) {
-    const int s = m.cell_start[cyi * m.W + cr.cx0];
-    const int e = m.cell_start[cyi * m.W + cr.cx1 + 1];
-    for (int i = s + lane; i < e; i += WAVE) {
-      const float px = m.x[i], py = m.y[i];
-      const float ddx = px - cx, ddy = py - cy;
-      const float d2 = ddx * ddx + ddy * ddy;
-      if (d2 <= a2) {
-        in_range++;
-        const float X = r00 * ddx + r01 * ddy;
-        const float Y = r10 * ddx + r11 * ddy;
-        bool keep = is_circle;
-        if (!is_circle) keep = (X * X) * bb + (Y * Y) * a2 < aabb;
-        if (keep) {
-          kept++;
-          const double xd = (double)X, yd = (double)Y, zd = (double)m.z[i] - (double)z1;
-          s_x += xd;
-          s_y += yd;
-          s_z += zd;
-          s_xx += xd * xd;
-          s_xy += xd * yd;
-          s_xz += xd * zd;
-          s_yy += yd * yd;
-          s_yz += yd * zd;
-          s_zz += zd * zd;
-        }
-      }
-    }
-  }
-  in_range = wave_sum(in_range);
-  kept = wave_sum(kept);
-  hits += (unsigned long long)in_range;
-  if (hit_counter && lane == 0) atomicAdd(hit_counter, hits);
-  o.n_pts = kept;
-  if (in_range == 0) {
-    o.status = EDGE_EMPTY | uncertain;
-    return o;
-  }
-  if (kept < 3) {
-    o.status = EDGE_FEW | uncertain;
-    return o;
-  }
-  s_x = wave_sum(s_x);
-  s_y = wave_sum(s_y);
-  s_z = wave_sum(s_z);
-  s_xx = wave_sum(s_xx);
-  s_xy = wave_sum(s_xy);
-  s_xz = wave_sum(s_xz);
-  s_yy = wave_sum(s_yy);
-  s_yz = wave_sum(s_yz);
-  s_zz = wave_sum(s_zz);
-
-  // covariance = centred^T * centred / (n - 1)  (trg.cpp:337-338), fp64 then rounded once
-  const double n = (double)kept;
-  const double mx = s_x / n, my = s_y / n, mz = s_z / n;
-  const double inv = 1.0 / (double)(kept - 1);
-  float cov[3][3];
-  cov[0][0] = (float)((s_xx - n * mx * mx) * inv);
-  cov[0][1] = (float)((s_xy - n * mx * my) * inv);
-  cov[0][2] = (float)((s_xz - n * mx * mz) * inv);
-  cov[1][1] = (float)((s_yy - n * my * my) * inv);
-  cov[1][2] = (float)((s_yz - n * my * mz) * inv);
-  cov[2][2] = (float)((s_zz - n * mz * mz) * inv);
-  cov[1][0] = cov[0][1];
-  cov[2][0] = cov[0][2];
-  cov[2][1] = cov[1][2];
-
+// covariance -> risk weight: JacobiSVD(cov).matrixU().normalized(), |z components| of the two
+// leading singular vectors, 0.8/0.2 blend, < 0.1 clamp (trg.cpp:339-363)
+__device__ float risk_weight(const float cov[3][3], int &clamped) {
   float U[3][3];
   svd_u3(cov, U);
-  // eigenvectors = U.normalized()  (divides by the Frobenius norm, trg.cpp:340)
   float fro = 0.0f;
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc)
@@ -608,14 +463,380 @@ __device__ EdgeOut edge_eval(const MapView &m, const QueryParams &p, float x1, f
   if (ver < 0.0f) ver = -e21;
   const float ratio = 0.8f;
   float w = ratio * hor + (1 - ratio) * ver;
-  int clamped = 0;
+  clamped = 0;
   if ((double)w < 0.1) {
     w = 0.0f;
     clamped = EDGE_CLAMPED;
   }
-  o.weight = w;
-  o.status = EDGE_OK | uncertain | clamped;
+  return w;
+}
+
+// ---- edge evaluation -----------------------------------------------------------------------------
+// Phase 1 (one wave per edge) produces the "mid" record: status, point count, dist and the 3x3
+// covariance; phase 2 (k_edge_finish, one THREAD per edge) runs the SVD.  Splitting them keeps the
+// serial ~500-flop Jacobi chain off the 64-lane gather waves.
+constexpr int MID_STRIDE = 12;  // dwords per mid record: status n_pts dist c00 c01 c02 c11 c12 c22 pad*3
+
+struct EdgeGeom {
+  float dist, dirx, diry, cx, cy;
+  int uncertain;
+  bool gated;
+};
+
+__device__ __forceinline__ EdgeGeom edge_geometry(const QueryParams &p, float x1, float y1, float z1,
+                                                  float x2, float y2, float z2) {
+  EdgeGeom g;
+  const float ex = x1 - x2, ey = y1 - y2;
+  g.dist = sqrtf(ex * ex + ey * ey);  // (node1.head(2) - node2.head(2)).norm()
+  // slope gate, trg.cpp:269-274: atan2f(|dz|, dist) > atan2f(h, r).  atan2 is monotone in the
+  // ratio, so the exact rational comparison |dz| * r  vs  h * dist decides it whenever the two
+  // sides differ by more than 1e-4 relative (fp32 atan2f error is ~1e-7); the sliver in between
+  // is flagged and the host applies the reference's own libm comparison.
+  g.uncertain = 0;
+  g.gated = false;
+  const double lhs = (double)fabsf(z1 - z2) * (double)p.robot_size;
+  const double rhs = (double)p.height_threshold * (double)g.dist;
+  if (lhs > rhs * (1.0 + 1e-4)) {
+    g.gated = true;
+  } else if (!(lhs < rhs * (1.0 - 1e-4))) {
+    g.uncertain = EDGE_GATE_UNCERTAIN;
+  }
+  // dir = (node2 - node1).normalized(); center = node1 + 0.5 * dist * dir  (trg.cpp:277-278)
+  const float dx = x2 - x1, dy = y2 - y1;
+  const float sq = dx * dx + dy * dy;
+  g.dirx = dx;
+  g.diry = dy;
+  if (sq > 0.0f) {
+    const float nrm = sqrtf(sq);
+    g.dirx = dx / nrm;
+    g.diry = dy / nrm;
+  }
+  const float half = 0.5f * g.dist;
+  g.cx = x1 + half * g.dirx;
+  g.cy = y1 + half * g.diry;
+  return g;
+}
+
+struct Moments {
+  double s_x = 0, s_y = 0, s_z = 0, s_xx = 0, s_xy = 0, s_xz = 0, s_yy = 0, s_yz = 0, s_zz = 0;
+  int kept = 0, in_range = 0;
+};
+
+struct EllipseParams {
+  float cx, cy, a2, bb, aabb, r00, r01, r10, r11, z_ref;
+  bool is_circle;
+};
+
+// one candidate point of the ellipse gather (trg.cpp:309-325); moments in fp64, z shifted
+__device__ __forceinline__ void ellipse_point(const EllipseParams &ep, float px, float py, float pz,
+                                              Moments &mo) {
+  const float ddx = px - ep.cx, ddy = py - ep.cy;
+  const float d2 = ddx * ddx + ddy * ddy;
+  if (d2 <= ep.a2) {
+    mo.in_range++;
+    const float X = ep.r00 * ddx + ep.r01 * ddy;
+    const float Y = ep.r10 * ddx + ep.r11 * ddy;
+    bool keep = ep.is_circle;
+    if (!ep.is_circle) keep = (X * X) * ep.bb + (Y * Y) * ep.a2 < ep.aabb;
+    if (keep) {
+      mo.kept++;
+      const double xd = (double)X, yd = (double)Y, zd = (double)pz - (double)ep.z_ref;
+      mo.s_x += xd;
+      mo.s_y += yd;
+      mo.s_z += zd;
+      mo.s_xx += xd * xd;
+      mo.s_xy += xd * yd;
+      mo.s_xz += xd * zd;
+      mo.s_yy += yd * yd;
+      mo.s_yz += yd * zd;
+      mo.s_zz += zd * zd;
+    }
+  }
+}
+
+// ---- LDS-staged neighbour tile -------------------------------------------------------------------
+// All map queries of one edge (the segment-walk discs and the ellipse gather) fall inside one
+// small box.  The wave loads the candidate points of that box ONCE -- every row segment is a
+// contiguous range, all loads are issued back to back -- into a per-wave LDS tile, and every
+// query then scans the tile instead of going back to global memory.
+constexpr int TCAP = 512;            // points per tile (x, y, z) and entries of the hit buffer
+constexpr int TITER = TCAP / WAVE;   // 8
+constexpr int MAXROWS = 32;
+
+struct Tile {
+  float *x, *y, *z, *zb;
+};
+
+// returns the number of staged candidates, or -1 when the box does not fit (caller falls back)
+__device__ int stage_tile(const MapView &m, const CellRange &c, const Tile &t) {
+  const int lane = lane_id();
+  const int nrows = c.cy1 - c.cy0 + 1;
+  if (nrows > MAXROWS) return -1;
+  int s = 0, e = 0;
+  if (lane < nrows) {
+    const int base = (c.cy0 + lane) * m.W;
+    s = m.cell_start[base + c.cx0];
+    e = m.cell_start[base + c.cx1 + 1];
+  }
+  const int len = e - s;
+  int inc = len;  // inclusive prefix of row lengths over lanes
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const int up = __shfl_up(inc, d);
+    if (lane >= d) inc += up;
+  }
+  const int total = __shfl(inc, WAVE - 1);
+  if (total > TCAP) return -1;
+  const int excl = inc - len;
+  float rx[TITER], ry[TITER], rz[TITER];
+#pragma unroll
+  for (int i = 0; i < TITER; ++i) {
+    rx[i] = ry[i] = rz[i] = 0.0f;
+    if (i * WAVE < total) {  // wave-uniform
+      const int tt = lane + i * WAVE;
+      const bool act = tt < total;
+      const int tq = act ? tt : 0;
+      int row = 0;
+      for (int l = 0; l < nrows; ++l) row += (tq >= __shfl(inc, l));
+      const int src = __shfl(s, row) + (tq - __shfl(excl, row));
+      if (act) {
+        rx[i] = m.x[src];
+        ry[i] = m.y[src];
+        rz[i] = m.z[src];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TITER; ++i) {
+    const int tt = lane + i * WAVE;
+    if (tt < total) {
+      t.x[tt] = rx[i];
+      t.y[tt] = ry[i];
+      t.z[tt] = rz[i];
+    }
+  }
+  wave_lds_sync();
+  return total;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// k-th smallest of zb[0..n) by rank counting, then #{|z - z_med| > h}  (trg.cpp:763-772)
+__device__ int median_count(const float *zb, int n, float h) {
+  const int lane = lane_id();
+  const int k = n / 2;
+  float mine = 0.0f;
+  bool found = false;
+  for (int i = lane; i < n; i += WAVE) {
+    const float zi = zb[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float zj = zb[j];
+      rank += (zj < zi) || (zj == zi && j < i);
+    }
+    if (rank == k) {
+      mine = zi;
+      found = true;
+    }
+  }
+  const unsigned long long who = __ballot(found);
+  const float zmed = who ? __shfl(mine, __ffsll((long long)who) - 1) : zb[0];
+  int cnt = 0;
+  for (int i = lane; i < n; i += WAVE) cnt += fabsf(zb[i] - zmed) > h;
+  return wave_sum(cnt);
+}
+
+// isCollision of one disc, candidates read from the tile.  n_out = points in the disc.
+__device__ bool tile_disc_collides(const Tile &t, int T, float qx, float qy, float r, float h,
+                                   float threshold, int &n_out) {
+  const int lane = lane_id();
+  const float r2 = r * r;
+  int n = 0;
+  float zmin = FLT_MAX, zmax = -FLT_MAX;
+  for (int base = 0; base < T; base += WAVE) {
+    const int i = base + lane;
+    bool hit = false;
+    float z = 0.0f;
+    if (i < T) {
+      const float dx = t.x[i] - qx;
+      const float dy = t.y[i] - qy;
+      z = t.z[i];
+      const float d2 = dx * dx + dy * dy;
+      hit = d2 <= r2;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (hit) {
+      t.zb[n + __popcll(mask & lanemask_lt())] = z;
+      zmin = fminf(zmin, z);
+      zmax = fmaxf(zmax, z);
+    }
+    n += __popcll(mask);
+  }
+  n_out = n;
+  if (n == 0) return true;  // trg.cpp:749-752
+  zmin = wave_min(zmin);
+  zmax = wave_max(zmax);
+  int cnt = 0;
+  // every |z - z_med| <= zmax - zmin (rounding is monotone), so a flat disc needs no median
+  if (!(zmax - zmin <= h)) {
+    wave_lds_sync();
+    cnt = median_count(t.zb, n, h);
+    wave_lds_sync();
+  }
+  const float ratio = (float)cnt / (float)n;
+  return ratio > threshold;
+}
+
+struct EdgeMidOut {
+  int status, n_pts;
+  float dist;
+  float c[6];
+  int hits;  // map points inside this edge's query radii (instrumentation)
+};
+
+// One wave: the position-only part of TRG::wireEdge up to the covariance (trg.cpp:269-338).
+__device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float x1, float y1,
+                                  float z1, float x2, float y2, float z2, const Tile &tile,
+                                  float *zbuf_big, DeviceCounters *ctr) {
+  const int lane = lane_id();
+  EdgeMidOut o;
+  o.n_pts = 0;
+  o.hits = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o.c[k] = 0.0f;
+  const EdgeGeom g = edge_geometry(p, x1, y1, z1, x2, y2, z2);
+  o.dist = g.dist;
+  if (g.gated) {
+    o.status = EDGE_GATE;
+    return o;
+  }
+
+  // ellipse with foci at the two nodes, trg.cpp:291-297
+  const float c = 0.5f * g.dist;
+  const float b = p.robot_size;
+  float a = b;
+  if (c >= b) a = sqrtf(c * c + b * b);
+  EllipseParams ep;
+  ep.cx = g.cx;
+  ep.cy = g.cy;
+  ep.is_circle = (a == b);
+  ep.r00 = g.dirx;  // R << dir.x, -dir.y, dir.y, dir.x  (trg.cpp:302-303)
+  ep.r01 = -g.diry;
+  ep.r10 = g.diry;
+  ep.r11 = g.dirx;
+  ep.a2 = a * a;
+  ep.bb = b * b;
+  ep.aabb = a * a * b * b;
+  ep.z_ref = z1;
+
+  // box holding every query of this edge: the capsule around the segment and the ellipse disc
+  CellRange box;
+  {
+    const float rp = p.robot_size * 1.001f + 1e-6f;
+    const float ap = a * 1.001f + 1e-6f;
+    const float xlo = fminf(fminf(x1, x2) - rp, g.cx - ap), xhi = fmaxf(fmaxf(x1, x2) + rp, g.cx + ap);
+    const float ylo = fminf(fminf(y1, y2) - rp, g.cy - ap), yhi = fmaxf(fmaxf(y1, y2) + rp, g.cy + ap);
+    box.cx0 = cell_coord(xlo, m.x0, m.inv_g, m.W);
+    box.cx1 = cell_coord(xhi, m.x0, m.inv_g, m.W);
+    box.cy0 = cell_coord(ylo, m.y0, m.inv_g, m.H);
+    box.cy1 = cell_coord(yhi, m.y0, m.inv_g, m.H);
+  }
+  const int T = stage_tile(m, box, tile);
+
+  unsigned long long hits = 0;
+  // segment walk, trg.cpp:282-288 (float accumulation of i is part of the semantics)
+  const float ds = p.robot_size * 0.5f;
+  int guard = 0;
+  for (float i = 0; i < g.dist; i += ds) {
+    const float qx = x1 + i * g.dirx;
+    const float qy = y1 + i * g.diry;
+    bool col;
+    int n = 0;
+    if (T >= 0) {
+      col = tile_disc_collides(tile, T, qx, qy, p.robot_size, p.height_threshold,
+                               p.collision_threshold, n);
+    } else {
+      const Disc d = disc_query<false>(m, qx, qy, p.robot_size, p.height_threshold, zbuf_big, ctr);
+      n = d.n;
+      col = disc_collides(d, p.collision_threshold);
+    }
+    hits += (unsigned long long)n;
+    if (col) {
+      o.status = EDGE_SEG | g.uncertain;
+      o.hits = (int)hits;
+      return o;
+    }
+    if (++guard > 100000 || !(ds > 0.0f)) break;
+  }
+
+  // gather + rotate + filter (trg.cpp:304-325)
+  Moments mo;
+  if (T >= 0) {
+    for (int i = lane; i < T; i += WAVE) ellipse_point(ep, tile.x[i], tile.y[i], tile.z[i], mo);
+  } else {
+    const CellRange cr = cells_for(m, g.cx, g.cy, a);
+    for (int cyi = cr.cy0; cyi <= cr.cy1; ++cyi) {
+      const int s = m.cell_start[cyi * m.W + cr.cx0];
+      const int e = m.cell_start[cyi * m.W + cr.cx1 + 1];
+      for (int i = s + lane; i < e; i += WAVE) ellipse_point(ep, m.x[i], m.y[i], m.z[i], mo);
+    }
+  }
+  const int in_range = wave_sum(mo.in_range);
+  const int kept = wave_sum(mo.kept);
+  hits += (unsigned long long)in_range;
+  o.hits = (int)hits;
+  o.n_pts = kept;
+  if (in_range == 0) {
+    o.status = EDGE_EMPTY | g.uncertain;
+    return o;
+  }
+  if (kept < 3) {
+    o.status = EDGE_FEW | g.uncertain;
+    return o;
+  }
+  const double s_x = wave_sum(mo.s_x), s_y = wave_sum(mo.s_y), s_z = wave_sum(mo.s_z);
+  const double s_xx = wave_sum(mo.s_xx), s_xy = wave_sum(mo.s_xy), s_xz = wave_sum(mo.s_xz);
+  const double s_yy = wave_sum(mo.s_yy), s_yz = wave_sum(mo.s_yz), s_zz = wave_sum(mo.s_zz);
+  // covariance = centred^T * centred / (n - 1)  (trg.cpp:337-338), fp64 then rounded once
+  const double n = (double)kept;
+  const double mx = s_x / n, my = s_y / n, mz = s_z / n;
+  const double inv = 1.0 / (double)(kept - 1);
+  o.c[0] = (float)((s_xx - n * mx * mx) * inv);
+  o.c[1] = (float)((s_xy - n * mx * my) * inv);
+  o.c[2] = (float)((s_xz - n * mx * mz) * inv);
+  o.c[3] = (float)((s_yy - n * my * my) * inv);
+  o.c[4] = (float)((s_yz - n * my * mz) * inv);
+  o.c[5] = (float)((s_zz - n * mz * mz) * inv);
+  o.status = EDGE_OK | g.uncertain;
   return o;
+}
+
+// lanes 0..8 of the wave store one mid record as a single contiguous 36-byte write
+__device__ __forceinline__ void store_mid(float *mid, int q, const EdgeMidOut &o) {
+  const int lane = lane_id();
+  if (lane < 10) {
+    float v;
+    switch (lane) {
+      case 0: v = __int_as_float(o.status); break;
+      case 1: v = __int_as_float(o.n_pts); break;
+      case 2: v = o.dist; break;
+      default: v = o.c[0]; break;
+    }
+#pragma unroll
+    for (int k = 1; k < 6; ++k)
+      if (lane == 3 + k) v = o.c[k];
+    if (lane == 9) v = __int_as_float(o.hits);
+    mid[(size_t)q * MID_STRIDE + lane] = v;
+  }
 }
 
 // ---- murmur-style counter hash shared with the oracle's sampler ------------------------------
@@ -832,36 +1053,40 @@ __global__ __launch_bounds__(QW *WAVE) void k_probe_nearest_z(MapView m, QueryPa
   if (lane_id() == 0) {
     z[q] = ok ? zz : 0.0f;
     if (found) found[q] = ok ? 1 : 0;
-    if (tie && ctr) atomicAdd(&ctr->nn_ties, 1ull);
+    if (tie && ctr) atomicAdd(&ctr[blockIdx.x % COUNTER_SHARDS].nn_ties, 1ull);
   }
 }
 
+// LDS per wave of the edge kernels: x, y, z tile + hit buffer (4 * TCAP floats = 8 KB); the hit
+// buffer doubles as the scratch of the global-memory fallback, whose capacity is therefore TCAP.
+static_assert(HCAP >= TCAP, "fallback hit buffer");
+struct EdgeLds {
+  float x[QW][TCAP], y[QW][TCAP], z[QW][TCAP], zb[QW][HCAP];
+};
+
 __global__ __launch_bounds__(QW *WAVE) void k_edges(MapView m, QueryParams p, const float *p1,
-                                                    const float *p2, int count, int *status,
-                                                    int *n_pts, float *weight, float *dist,
+                                                    const float *p2, int count, float *mid,
                                                     DeviceCounters *ctr) {
-  __shared__ float ztile[QW][HCAP];
+  __shared__ EdgeLds lds;
   const int w = threadIdx.x >> 6;
   const int q = blockIdx.x * QW + w;
   if (q >= count) return;
-  const EdgeOut o = edge_eval(m, p, p1[3 * q], p1[3 * q + 1], p1[3 * q + 2], p2[3 * q],
-                              p2[3 * q + 1], p2[3 * q + 2], ztile[w], ctr,
-                              ctr ? &ctr->edge_hits : nullptr);
-  if (lane_id() == 0) {
-    status[q] = o.status;
-    n_pts[q] = o.n_pts;
-    weight[q] = o.weight;
-    dist[q] = o.dist;
-  }
+  Tile t;
+  t.x = lds.x[w];
+  t.y = lds.y[w];
+  t.z = lds.z[w];
+  t.zb = lds.zb[w];
+  const EdgeMidOut o = edge_gather(m, p, p1[3 * q], p1[3 * q + 1], p1[3 * q + 2], p2[3 * q],
+                                   p2[3 * q + 1], p2[3 * q + 2], t, lds.zb[w], ctr);
+  store_mid(mid, q, o);
 }
 
 __global__ __launch_bounds__(QW *WAVE) void k_spec_edges(MapView m, QueryParams p,
                                                          const float *node_xyz, int count,
                                                          const int *n_acc, const float *sx,
                                                          const float *sy, const float *sz,
-                                                         int *status, int *n_pts, float *weight,
-                                                         float *dist, DeviceCounters *ctr) {
-  __shared__ float ztile[QW][HCAP];
+                                                         float *mid, DeviceCounters *ctr) {
+  __shared__ EdgeLds lds;
   const int w = threadIdx.x >> 6;
   const int slot = blockIdx.x * QW + w;
   const int S = p.sample_num;
@@ -869,15 +1094,60 @@ __global__ __launch_bounds__(QW *WAVE) void k_spec_edges(MapView m, QueryParams 
   const int node = slot / S;
   const int j = slot - node * S;
   if (j >= n_acc[node]) return;
-  const EdgeOut o = edge_eval(m, p, node_xyz[3 * node], node_xyz[3 * node + 1],
-                              node_xyz[3 * node + 2], sx[slot], sy[slot], sz[slot], ztile[w], ctr,
-                              ctr ? &ctr->spec_hits : nullptr);
-  if (lane_id() == 0) {
-    status[slot] = o.status;
-    n_pts[slot] = o.n_pts;
-    weight[slot] = o.weight;
-    dist[slot] = o.dist;
+  Tile t;
+  t.x = lds.x[w];
+  t.y = lds.y[w];
+  t.z = lds.z[w];
+  t.zb = lds.zb[w];
+  const EdgeMidOut o = edge_gather(m, p, node_xyz[3 * node], node_xyz[3 * node + 1],
+                                   node_xyz[3 * node + 2], sx[slot], sy[slot], sz[slot], t,
+                                   lds.zb[w], ctr);
+  store_mid(mid, slot, o);
+}
+
+// Phase 2: one thread per edge: covariance -> SVD -> risk weight (trg.cpp:339-363).
+// valid_n_acc != nullptr: slot layout of a chunk (node * S + j), slots with j >= n_acc are skipped.
+__global__ __launch_bounds__(256) void k_edge_finish(const float *mid, int count, int S,
+                                                     const int *valid_n_acc, int *status,
+                                                     int *n_pts, float *weight, float *dist,
+                                                     DeviceCounters *ctr, int which_counter) {
+  __shared__ int wave_hits[4];
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = q < count;
+  if (live && valid_n_acc) {
+    const int node = q / S;
+    live = (q - node * S) < valid_n_acc[node];
   }
+  const float *r = mid + (size_t)(live ? q : 0) * MID_STRIDE;
+  // one atomic per block for the instrumentation counter
+  const int h = wave_sum(live ? __float_as_int(r[9]) : 0);
+  if (lane_id() == 0) wave_hits[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0 && ctr) {
+    const unsigned long long tot =
+        (unsigned long long)(wave_hits[0] + wave_hits[1] + wave_hits[2] + wave_hits[3]);
+    DeviceCounters *c = &ctr[blockIdx.x % COUNTER_SHARDS];
+    atomicAdd(which_counter ? &c->spec_hits : &c->edge_hits, tot);
+  }
+  if (!live) return;
+  int st = __float_as_int(r[0]);
+  float w = 0.0f;
+  if ((st & EDGE_STATUS_MASK) == EDGE_OK) {
+    float cov[3][3];
+    cov[0][0] = r[3];
+    cov[0][1] = cov[1][0] = r[4];
+    cov[0][2] = cov[2][0] = r[5];
+    cov[1][1] = r[6];
+    cov[1][2] = cov[2][1] = r[7];
+    cov[2][2] = r[8];
+    int clamped = 0;
+    w = risk_weight(cov, clamped);
+    st |= clamped;
+  }
+  status[q] = st;
+  if (n_pts) n_pts[q] = __float_as_int(r[1]);
+  weight[q] = w;
+  dist[q] = r[2];
 }
 
 constexpr int SW = 8;  // waves per block in the sampling kernel = trials evaluated per round
@@ -896,6 +1166,8 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
   __shared__ float ztile[SW][HCAP];
   __shared__ int r_col[SW];
   __shared__ float r_x[SW], r_y[SW], r_z[SW];
+  __shared__ unsigned long long r_hits[SW];
+  __shared__ int r_ties[SW];
   const int node = blockIdx.x;
   if (node >= count) return;
   const int w = threadIdx.x >> 6;
@@ -945,9 +1217,21 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
     n_acc_out[node] = n_acc;
     n_draws_out[node] = draws;
   }
-  if (ctr && lane == 0) {
-    atomicAdd(&ctr->sample_hits, hits);
-    if (ties) atomicAdd(&ctr->nn_ties, (unsigned long long)ties);
+  if (lane == 0) {
+    r_hits[w] = hits;
+    r_ties[w] = ties;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && ctr) {
+    unsigned long long th = 0;
+    int tt = 0;
+    for (int i = 0; i < SW; ++i) {
+      th += r_hits[i];
+      tt += r_ties[i];
+    }
+    DeviceCounters *c = &ctr[blockIdx.x % COUNTER_SHARDS];
+    atomicAdd(&c->sample_hits, th);
+    if (tt) atomicAdd(&c->nn_ties, (unsigned long long)tt);
   }
 }
 
@@ -1006,11 +1290,13 @@ void launch_probe_nearest_z(const MapView &m, QueryParams p, const float *d_xy, 
                      d_xy, count, z, found, ctr);
 }
 void launch_edges(const MapView &m, QueryParams p, const float *d_p1, const float *d_p2, int count,
-                  int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
-                  hipStream_t s) {
+                  float *mid, int *status, int *n_pts, float *weight, float *dist,
+                  DeviceCounters *ctr, hipStream_t s) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_edges, dim3((count + QW - 1) / QW), dim3(QW * WAVE), 0, s, m, p, d_p1, d_p2,
-                     count, status, n_pts, weight, dist, ctr);
+                     count, mid, ctr);
+  hipLaunchKernelGGL(k_edge_finish, dim3((count + 255) / 256), dim3(256), 0, s, mid, count, 1,
+                     (const int *)nullptr, status, n_pts, weight, dist, ctr, 0);
 }
 void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
                          int table_bits, uint32_t seed, uint32_t epoch, const float *node_xy,
@@ -1023,12 +1309,16 @@ void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, co
 }
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
                        const int *n_acc, const float *sx, const float *sy, const float *sz,
-                       int *status, int *n_pts, float *weight, float *dist, DeviceCounters *ctr,
-                       hipStream_t s) {
+                       float *mid, int *status, int *n_pts, float *weight, float *dist,
+                       DeviceCounters *ctr, hipStream_t s) {
   if (count <= 0) return;
   const int slots = count * p.sample_num;
   hipLaunchKernelGGL(k_spec_edges, dim3((slots + QW - 1) / QW), dim3(QW * WAVE), 0, s, m, p,
-                     node_xyz, count, n_acc, sx, sy, sz, status, n_pts, weight, dist, ctr);
+                     node_xyz, count, n_acc, sx, sy, sz, mid, ctr);
+  hipLaunchKernelGGL(k_edge_finish, dim3((slots + 255) / 256), dim3(256), 0, s, mid, slots,
+                     p.sample_num, n_acc, status, n_pts, weight, dist, ctr, 1);
 }
+
+size_t edge_mid_floats(size_t edges) { return edges * MID_STRIDE; }
 
 }  // namespace trg
