@@ -125,6 +125,9 @@ typedef struct TrgStats {
   double ms_replay_host;
   double ms_finalize_host;
   double ms_wait_gpu;
+  uint64_t bfs_levels;         /* BFS depth of the last build (device-resident path) */
+  uint64_t used_device_bfs;    /* 1: BFS + CSR ran on the GPU; 0: host replay */
+  uint64_t bfs_fallbacks;      /* device path declined and the host replay redid the build */
 } TrgStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -186,6 +189,15 @@ TrgStatus trg_engine_edge_risk_batch(TrgEngine *e, TrgKind map, const float *p1_
                                      float *weight, float *dist);
 /* reference: TRG::isFrontier trg.cpp:780-803 */
 TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, int32_t *flag);
+
+/* ---- options ----------------------------------------------------------------------------------- */
+/* "replay" = "device" (default: BFS, dedupe and CSR on the GPU when expandGraph's step 3 is off,
+ * trg.cpp:429) | "host" (sequential replay on the host, the only mode for step-3 configs);
+ * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot).  Both modes give identical
+ * graphs; the env var TRG_REPLAY=host sets the default. */
+TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value);
+/* why the last build fell back from the device path to the host replay ("" if it did not) */
+const char *trg_engine_fallback_reason(const TrgEngine *e);
 
 /* ---- instrumentation ------------------------------------------------------------------------- */
 TrgStatus trg_engine_get_stats(const TrgEngine *e, TrgStats *out);

@@ -25,6 +25,7 @@ def test_mountain_golden(oa, synth):
     cloud = synth.mountain_cloud(nx, ny, seed=seed, amplitude=5.0, wavelength=14.0)
     e = trg_planner.Engine(**oa.MOUNTAIN)
     e.set_sampler(7, 16)
+    e.set_option("keep_preclean", 1)
     e.set_global_map(cloud)
     f, c, n = e.is_collision(gold["m_xy"])
     assert np.array_equal(f, gold["m_flag"]) and np.array_equal(c, gold["m_cnt"])
@@ -53,6 +54,7 @@ def test_indoor_golden(oa):
     gold = np.load(GOLD)
     e = trg_planner.Engine(**oa.INDOOR)
     e.set_sampler(5, 16)
+    e.set_option("keep_preclean", 1)
     e.set_global_map(gold["i_cloud"])
     e.init_graph([1.5, 1.5, 0.0])
     _cmp(e.graph("preclean"), gold, "i_pre")

@@ -140,9 +140,12 @@ def test_edge_risk_parity(oa, request, cloud_name):
     assert float(dw2.max()) <= 2e-6, float(dw2.max())
 
 
-def _build_both(oa, prm, cloud, start, seed):
+def _build_both(oa, prm, cloud, start, seed, replay=None):
     e = _engine(prm)
     e.set_sampler(seed, 16)
+    e.set_option("keep_preclean", 1)
+    if replay:
+        e.set_option("replay", replay)
     e.set_global_map(cloud)
     e.init_graph(start)
     o = oa.Oracle(**prm)
@@ -152,8 +155,9 @@ def _build_both(oa, prm, cloud, start, seed):
     return e, o
 
 
+@pytest.mark.parametrize("replay", ["device", "host"])
 @pytest.mark.parametrize("case", ["mountain_rough_S7", "mountain_gentle_S16", "indoor_S15"])
-def test_init_graph_parity(oa, request, case):
+def test_init_graph_parity(oa, request, case, replay):
     if case == "mountain_rough_S7":
         cloud = request.getfixturevalue("mountain_small")
         prm = dict(oa.MOUNTAIN)
@@ -166,7 +170,11 @@ def test_init_graph_parity(oa, request, case):
         cloud = request.getfixturevalue("indoor_small")
         prm = dict(oa.INDOOR)
         start = [1.5, 1.5, 0.0]
-    e, o = _build_both(oa, prm, cloud, start, seed=7)
+    e, o = _build_both(oa, prm, cloud, start, seed=7, replay=replay)
+    used_device = e.stats()["used_device_bfs"]
+    # the device-resident BFS serves every config whose expandGraph step 3 is off (trg.cpp:429)
+    assert used_device == (1 if (replay == "device" and not case.startswith("indoor")) else 0), \
+        e.fallback_reason
     pre_e, pre_o = e.graph("preclean"), o.graph(1)
     assert pre_o.V > 200, pre_o.V
     assert_graph_equal(pre_e, pre_o, WEIGHT_TOL, allow_weight_outliers=max(2, pre_o.E // 500))
@@ -179,6 +187,7 @@ def test_init_graph_parity(oa, request, case):
     assert st["samples"] == c["samples"]
     assert st["created_nodes"] == c["created"]
     assert st["invalid_nodes"] == c["invalid_created"]
+    assert st["nn_ties"] == 0
     # invariants of the reference
     assert (ge.state != -1).all() and (np.diff(ge.rowptr) >= 1).all()
     assert (ge.dist < 2.5 * prm["expand_dist"]).all()
@@ -201,3 +210,20 @@ def test_plan_parity(oa, mountain_gentle):
         assert abs(ie.avg_risk - io[2]) <= WEIGHT_TOL
         re_, ro = e.refine_path(pe), oa.Oracle.refine(po)
         assert np.array_equal(re_.view(np.uint32), ro.view(np.uint32))
+
+
+def test_repeated_builds_are_identical(oa, mountain_small):
+    """Same engine, same inputs, twice: the graph (including the container-order renumbering of
+    cleanGraph, which depends on the hash table's bucket history) must match an oracle that went
+    through the same two calls."""
+    prm = dict(oa.MOUNTAIN)
+    e = _engine(prm)
+    e.set_sampler(11, 16)
+    e.set_global_map(mountain_small)
+    o = oa.Oracle(**prm)
+    o.set_sampler(11, 0, 16)
+    o.set_global_map(mountain_small)
+    for start in ([15.0, 15.0, 0.0], [9.0, 21.0, 0.0]):
+        e.init_graph(start)
+        assert o.init_graph(start)
+        assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)

@@ -174,6 +174,8 @@ struct EdgeBatch {
   float *d_mid = nullptr;
 };
 
+struct BfsBuffers;  // device-resident BFS state (trg_engine_bfs.inc)
+
 }  // namespace
 
 struct TrgEngine {
@@ -232,7 +234,12 @@ struct TrgEngine {
   size_t sy_cap = 0;
 
   Csr csr_global, csr_pre, csr_local;
-  bool keep_preclean = true;
+  bool keep_preclean = false;    // instrumentation: snapshot the graph before cleanGraph
+  bool use_device_bfs = true;    // device-resident BFS when expandGraph's step 3 is disabled
+  bool pool_valid = true;        // e->edges mirrors csr_global
+  bool host_grid_valid = true;   // e->grid holds the current node set
+  BfsBuffers *bfs = nullptr;
+  std::string bfs_fallback_reason;
   TrgStats stats{};
 
   // goal state (trg.h:121-126)
@@ -1107,6 +1114,8 @@ void clean_graph(TrgEngine *e) {
   for (auto &kv : e->order_map) e->kd_insert_order.push_back(kv.first);
   e->kd_valid = false;
   grid_rebuild(e);
+  e->host_grid_valid = true;
+  e->pool_valid = true;
 }
 
 void read_counters(TrgEngine *e) {
@@ -1165,6 +1174,27 @@ TrgStatus set_local_graph(TrgEngine *e) {
 
 }  // namespace
 
+#include "trg_engine_bfs.inc"
+
+namespace {
+// host-side edge pool / node grid rebuilt from the CSR after a device build (lazy)
+void ensure_pool(TrgEngine *e) {
+  if (e->pool_valid) return;
+  const Csr &g = e->csr_global;
+  const size_t V = g.state.size();
+  e->edges.reset(V);
+  e->edges.dst.reserve(g.col.size());
+  for (size_t i = 0; i < V; ++i)
+    for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) e->edges.push((int)i, g.col[k], g.w[k], g.dist[k]);
+  e->pool_valid = true;
+}
+void ensure_host_grid(TrgEngine *e) {
+  if (e->host_grid_valid) return;
+  grid_rebuild(e);
+  e->host_grid_valid = true;
+}
+}  // namespace
+
 // =================================== C ABI ======================================================
 extern "C" {
 
@@ -1195,6 +1225,8 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
   // step 3 of expandGraph is compiled in or out by this fp comparison (trg.cpp:429)
   e->step3 = (e->prm.expand_dist - e->prm.robot_size) < 0.25 * e->prm.expand_dist;
   e->device_ok = true;
+  e->bfs = new BfsBuffers();
+  if (const char *env = getenv("TRG_REPLAY")) e->use_device_bfs = std::string(env) != "host";
   reset_graph_global(e);
   return TRG_OK;
 }
@@ -1227,6 +1259,10 @@ void trg_engine_destroy(TrgEngine *e) {
       if (b.d_mid) (void)hipFree(b.d_mid);
     }
     if (e->sy_mid) (void)hipFree(e->sy_mid);
+    if (e->bfs) {
+      e->bfs->release();
+      delete e->bfs;
+    }
     free_pinned(e->sy_in);
     free_pinned(e->sy_in2);
     free_pinned(e->sy_f0);
@@ -1326,15 +1362,16 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
   }
   HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
   reset_graph_global(e);
+  e->pool_valid = true;
   e->epoch = 0;
   e->calls.clear();
   e->pending_calls.clear();
-  grid_rebuild(e);
+  e->csr_pre.clear();
 
   // root seeding, trg.cpp:44-56
   e->root_pos[0] = start_xyz[0];
   e->root_pos[1] = start_xyz[1];
-  float rx = e->root_pos[0], ry = e->root_pos[1];
+  float rx = e->root_pos[0], ry = e->root_pos[1], rz = 0.0f;
   rx = rx + e->prm.expand_dist;
   int cnt = 0;
   for (;;) {
@@ -1343,11 +1380,9 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     st = collision_sync(e, e->gmap, e->prm.collision_threshold, xy, 1, &flag, nullptr, nullptr);
     if (st != TRG_OK) return st;
     if (!flag) {
-      float z = 0;
       int32_t found = 0;
-      st = nearest_z_sync(e, e->gmap, xy, 1, &z, &found);
+      st = nearest_z_sync(e, e->gmap, xy, 1, &rz, &found);
       if (st != TRG_OK) return st;
-      add_node_host(e, rx, ry, z, TRG_NODE_VALID);
       break;
     }
     if (cnt > 100) return e->fail(TRG_ERR_NO_ROOT, "Failed to generate root node");
@@ -1357,6 +1392,25 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     cnt++;
   }
 
+  if (!e->step3 && e->use_device_bfs) {
+    st = build_graph_device(e, rx, ry, rz);
+    if (st == TRG_OK) {
+      read_counters(e);
+      e->stats.used_device_bfs = 1;
+      e->stats.ms_init_graph_total = ms_since(t_total);
+      return TRG_OK;
+    }
+    if (e->bfs_fallback_reason.empty()) return st;
+    // the device path declined (capacity, or an exact fp32 tie whose winner depends on the
+    // reference kd-tree's shape): redo the build with the host replay, which handles those
+    e->stats.bfs_fallbacks++;
+    HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
+    reset_graph_global(e);
+  }
+
+  grid_rebuild(e);
+  e->host_grid_valid = true;
+  add_node_host(e, rx, ry, rz, TRG_NODE_VALID);
   st = expand_bfs(e, e->node_id - 1);
   if (st != TRG_OK) return st;
   auto t_fin = Clock::now();
@@ -1372,14 +1426,34 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
   return TRG_OK;
 }
 
+TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value) {
+  if (!e || !key || !value) return TRG_ERR_INVALID_ARG;
+  const std::string k(key), v(value);
+  if (k == "replay") {
+    if (v == "host") e->use_device_bfs = false;
+    else if (v == "device") e->use_device_bfs = true;
+    else return e->fail(TRG_ERR_INVALID_ARG, "replay must be host or device");
+    return TRG_OK;
+  }
+  if (k == "keep_preclean") {
+    e->keep_preclean = v != "0";
+    return TRG_OK;
+  }
+  return e->fail(TRG_ERR_INVALID_ARG, "unknown option " + k);
+}
+
+const char *trg_engine_fallback_reason(const TrgEngine *e) {
+  return e ? e->bfs_fallback_reason.c_str() : "";
+}
+
 TrgStatus trg_engine_update_graph(TrgEngine *e) {
   REQUIRE_DEVICE(e);
   if (!e->gmap.valid) return e->fail(TRG_ERR_NO_MAP, "Map is empty");
   TrgStatus st = ensure_sampler(e, nullptr);
   if (st != TRG_OK) return st;
   e->epoch++;
-  const size_t first_call = e->calls.size();
-  (void)first_call;
+  ensure_pool(e);
+  ensure_host_grid(e);
   e->calls.clear();
   e->pending_calls.clear();
 
@@ -1438,12 +1512,13 @@ TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out) {
   Csr *c = nullptr;
   if (kind == TRG_KIND_GLOBAL) {
     c = &e->csr_global;
-    if (c->rowptr.empty() || c->state.size() != e->nx.size()) snapshot_csr(e, *c);
+    if (e->pool_valid && (c->rowptr.empty() || c->state.size() != e->nx.size())) snapshot_csr(e, *c);
   } else if (kind == TRG_KIND_PRECLEAN) {
     c = &e->csr_pre;
   } else {
     // local graph: the global rows of the local member nodes
     c = &e->csr_local;
+    ensure_pool(e);
     Csr full;
     snapshot_csr(e, full);
     c->clear();
@@ -1485,6 +1560,7 @@ TrgStatus trg_engine_save_json(TrgEngine *e, const char *path) {
   }
   std::ofstream f(p);
   if (!f) return e->fail(TRG_ERR_IO, "cannot open " + p);
+  ensure_pool(e);
   char buf[256];
   f << "{\n    \"edges\": [";
   // nodes/edges are listed in the node map's iteration order, like the reference
@@ -1647,6 +1723,8 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
   }
   e->kd_valid = false;
   grid_rebuild(e);
+  e->host_grid_valid = true;
+  e->pool_valid = true;
   snapshot_csr(e, e->csr_global);
   return TRG_OK;
 }
@@ -1659,6 +1737,7 @@ TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goa
   info->num_points = 0;
   const size_t V = e->nx.size();
   if (V == 0) return e->fail(TRG_ERR_NO_GRAPH, "graph is empty");
+  ensure_pool(e);
   kd_sync(e);
 
   // setGoal

@@ -93,4 +93,81 @@ void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, i
                        float *mid, int *status, int *n_pts, float *weight, float *dist,
                        DeviceCounters *ctr, hipStream_t s);
 
+// ---- device-resident BFS (trg_bfs.inc) ------------------------------------------------------------
+constexpr int BFS_NBMAX = 32;      // AVERAGE earlier-candidate list length the per-level pool holds
+constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, nodes are >= robot_size apart)
+constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
+enum : int {
+  BFS_CTR_V = 0, BFS_CTR_MNEXT = 1, BFS_CTR_NCAND = 2, BFS_CTR_NUNC = 3, BFS_CTR_ERR = 4,
+  BFS_CTR_NBPOOL = 5, BFS_CTR_COUNT = 8
+};
+enum : int {
+  BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
+  BFS_ERR_HASH = 16, BFS_ERR_LEVEL_TOO_BIG = 32, BFS_ERR_CLEAN = 64
+};
+enum : int { CALL_NONE = -2, CALL_PENDING = -1 };
+
+struct BfsDev {
+  // node store (creation order) and its hash grid
+  float *nx, *ny, *nz;
+  int *nstate;
+  int vcap;
+  int *gcnt, *gslots;
+  float gx0, gy0, ginv, gcell;
+  int GW, GH;
+  // frontier ping-pong
+  int *front_cur, *front_next;
+  int fcap;
+  // per frontier node
+  int *n_acc, *n_draws;
+  // per sample slot (fcap * S)
+  float *sx, *sy, *sz, *d0sq, *nb_d2;
+  int *nn0, *cls, *cand_off, *nb_cnt, *nb_off, *nb_idx;
+  long long nb_pool;  // entries in nb_idx / nb_d2
+  // per candidate
+  int *cand_slot, *c_status, *c_outcome, *c_target, *c_newid;
+  float *mid, *c_weight, *c_dist;
+  // uncertain slope gates for the host
+  int *unc_list;
+  float *unc_rec;
+  // candidate hash of the level
+  int *ht_key, *ht_val;
+  int ht_size;
+  // call log (one record per sample slot, in program order)
+  int *call_n1, *call_n2, *call_status;
+  float *call_w, *call_dist;
+  // counters
+  int *ctrs;
+  unsigned long long *stats64;  // draws, samples, created, invalid, spec evaluations
+};
+
+struct FinDev {
+  unsigned long long *ht_key;
+  int *ht_seq;
+  unsigned ht_size;
+  int *call_slot;
+  int *deg, *fill, *rowptr;
+  int *col, *seq;
+  float *w, *dist;
+};
+
+void launch_bfs_insert_nodes(const BfsDev &B, int first, int count, hipStream_t s);
+void launch_bfs_sample(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
+                       int table_bits, uint32_t seed, uint32_t epoch, const BfsDev &B, int count,
+                       DeviceCounters *ctr, hipStream_t s);
+// classify + candidate scan/fill + speculative parent edges (ends where the host must look at
+// BFS_CTR_NUNC); flag / scan_tmp: scratch of count*S+1 and count*S/2048+4 ints
+void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int count, int *flag,
+                        int *scan_tmp, DeviceCounters *ctr, hipStream_t s);
+// neighbour lists + resolve + call emission
+void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
+                        hipStream_t s);
+void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, long long base, int count,
+                       DeviceCounters *ctr, hipStream_t s);
+void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
+void launch_fin_scatter_sort(const FinDev &F, const BfsDev &B, long long ncalls, int V, hipStream_t s);
+void launch_fin_clean(const FinDev &F, const BfsDev &B, const int *new2old, const int *old2new, int Vn,
+                      int *deg_new, int *rowptr_new, int *scan_tmp, int *col, float *w, float *dist,
+                      float *xyz, int *state, hipStream_t s);
+
 }  // namespace trg

@@ -1162,7 +1162,8 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
                                                            const int *node_id, int count,
                                                            int *n_acc_out, int *n_draws_out,
                                                            float *sx, float *sy, float *sz,
-                                                           DeviceCounters *ctr) {
+                                                           DeviceCounters *ctr, const int *front,
+                                                           const float *gnx, const float *gny) {
   __shared__ float ztile[SW][HCAP];
   __shared__ int r_col[SW];
   __shared__ float r_x[SW], r_y[SW], r_z[SW];
@@ -1172,8 +1173,19 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
   if (node >= count) return;
   const int w = threadIdx.x >> 6;
   const int lane = lane_id();
-  const float px = node_xy[2 * node], py = node_xy[2 * node + 1];
-  const uint32_t id = (uint32_t)node_id[node];
+  // two addressing modes: chunk arrays (host replay) or frontier ids into the device node arrays
+  float px, py;
+  uint32_t id;
+  if (front) {
+    const int g = front[node];
+    px = gnx[g];
+    py = gny[g];
+    id = (uint32_t)g;
+  } else {
+    px = node_xy[2 * node];
+    py = node_xy[2 * node + 1];
+    id = (uint32_t)node_id[node];
+  }
   const int S = p.sample_num;
   const int max_trial_sample = 1000;
   int n_acc = 0, rejects = 0, draws = 0;
@@ -1234,6 +1246,8 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
     if (tt) atomicAdd(&c->nn_ties, (unsigned long long)tt);
   }
 }
+
+#include "trg_bfs.inc"
 
 inline int blocks_for(size_t n, int per_block, int cap) {
   size_t b = (n + per_block - 1) / per_block;
@@ -1305,7 +1319,7 @@ void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, co
   if (count <= 0) return;
   hipLaunchKernelGGL(k_sample_nodes, dim3(count), dim3(SW * WAVE), 0, s, m, p, cos_t, sin_t,
                      table_bits, seed, epoch, node_xy, node_id, count, n_acc, n_draws, sx, sy, sz,
-                     ctr);
+                     ctr, (const int *)nullptr, (const float *)nullptr, (const float *)nullptr);
 }
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
                        const int *n_acc, const float *sx, const float *sy, const float *sz,
@@ -1320,5 +1334,7 @@ void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, i
 }
 
 size_t edge_mid_floats(size_t edges) { return edges * MID_STRIDE; }
+
+#include "trg_bfs_launch.inc"
 
 }  // namespace trg

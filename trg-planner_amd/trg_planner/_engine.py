@@ -63,7 +63,8 @@ class TrgStats(C.Structure):
         ("launches_sample_kernel", C.c_uint64), ("launches_spec_kernel", C.c_uint64),
         ("launches_edge_kernel", C.c_uint64), ("ms_set_map_total", C.c_double),
         ("ms_init_graph_total", C.c_double), ("ms_replay_host", C.c_double),
-        ("ms_finalize_host", C.c_double), ("ms_wait_gpu", C.c_double)]
+        ("ms_finalize_host", C.c_double), ("ms_wait_gpu", C.c_double),
+        ("bfs_levels", C.c_uint64), ("used_device_bfs", C.c_uint64), ("bfs_fallbacks", C.c_uint64)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
@@ -75,14 +76,15 @@ EXPORTS = [
     "trg_engine_load_json", "trg_engine_plan", "trg_engine_refine_path",
     "trg_engine_is_collision_batch", "trg_engine_nearest_z_batch", "trg_engine_edge_risk_batch",
     "trg_engine_is_frontier_batch", "trg_engine_get_stats", "trg_engine_get_sampler_table",
-    "trg_engine_debug_map_index",
+    "trg_engine_debug_map_index", "trg_engine_set_option", "trg_engine_fallback_reason",
 ]
 
 
 def build_library(force=False):
     """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in ("trg_kernels.hip", "trg_kernels.h", "trg_engine.cpp",
-                                             "host_index.h")]
+                                             "host_index.h", "trg_bfs.inc", "trg_bfs_launch.inc",
+                                             "trg_engine_bfs.inc")]
     srcs.append(os.path.normpath(os.path.join(CSRC, "..", "..", "include", "trg_engine.h")))
     stale = force or not os.path.exists(LIB_PATH)
     if not stale:
@@ -133,6 +135,9 @@ def load_library():
     L.trg_engine_get_stats.argtypes = [vp, C.POINTER(TrgStats)]
     L.trg_engine_get_sampler_table.argtypes = [vp, fp, fp]
     L.trg_engine_debug_map_index.argtypes = [vp, C.c_int, fp, fp, fp, ip, ip, fp]
+    L.trg_engine_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.trg_engine_fallback_reason.argtypes = [vp]
+    L.trg_engine_fallback_reason.restype = C.c_char_p
     _lib = L
     return L
 
@@ -199,6 +204,13 @@ class Engine:
     @property
     def arch(self):
         return self.L.trg_engine_device_arch(self.h).decode()
+
+    def set_option(self, key, value):
+        self._chk(self.L.trg_engine_set_option(self.h, str(key).encode(), str(value).encode()))
+
+    @property
+    def fallback_reason(self):
+        return self.L.trg_engine_fallback_reason(self.h).decode()
 
     def set_sampler(self, seed=1, table_bits=16):
         self.sampler = TrgSampler(seed, table_bits)
