@@ -126,6 +126,7 @@ struct BfsDev {
   long long nb_pool;  // entries in nb_idx / nb_d2
   // per candidate
   int *cand_slot, *c_status, *c_outcome, *c_target, *c_newid;
+  int *newnode_slot;  // slot of the sample that created node V0 + k in the current level
   float *mid, *c_weight, *c_dist;
   // uncertain slope gates for the host
   int *unc_list;
@@ -160,8 +161,9 @@ void launch_bfs_sample(const MapView &m, QueryParams p, const float *cos_t, cons
 void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int count, int *flag,
                         int *scan_tmp, DeviceCounters *ctr, hipStream_t s);
 // neighbour lists + resolve + call emission
+constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-resident (<= 512 groups)
 void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
-                        hipStream_t s);
+                        int V0, int ncand_bound, hipStream_t s);
 void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, long long base, int count,
                        DeviceCounters *ctr, hipStream_t s);
 void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
