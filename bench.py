@@ -173,7 +173,9 @@ def main():
                 "ms_spec_kernel": st["ms_spec_kernel"], "ms_edge_kernel": st["ms_edge_kernel"],
                 "expanded_nodes": st["expanded_nodes"], "samples": st["samples"],
                 "edge_evals_gpu": st["edge_evals_gpu"], "nn_ties": st["nn_ties"],
-                "gate_uncertain": st["gate_uncertain"],
+                "gate_uncertain": st["gate_uncertain"], "bfs_levels": st["bfs_levels"],
+                "used_device_bfs": st["used_device_bfs"], "bfs_fallbacks": st["bfs_fallbacks"],
+                "bfs_max_spin": st["bfs_max_spin"],
             },
         }
         if not args.no_cpu_baseline and world == 1:

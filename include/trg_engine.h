@@ -128,6 +128,7 @@ typedef struct TrgStats {
   uint64_t bfs_levels;         /* BFS depth of the last build (device-resident path) */
   uint64_t used_device_bfs;    /* 1: BFS + CSR ran on the GPU; 0: host replay */
   uint64_t bfs_fallbacks;      /* device path declined and the host replay redid the build */
+  uint64_t bfs_max_spin;       /* longest dependency wait (poll iterations) in k_bfs_resolve */
 } TrgStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
