@@ -92,13 +92,15 @@ def main():
     import trg_planner
     from trg_planner import synth
 
+    from trg_planner import tiling
     nx, ny, S, label = WORKLOADS[args.workload]
-    # spatial tile of this rank: tiles sit side by side along x; same generator, seed + rank
-    origin = (rank * nx * 0.1, 0.0)
-    cloud = synth.mountain_cloud(nx, ny, seed=args.seed + rank, origin=origin)
+    # spatial tile of this rank (C4/C5-style tiling: 2x1, 2x2, 4x2 ...): same generator, seed + rank
+    tile = tiling.tile_of_rank(rank, world, nx, ny)
+    origin = tile["origin"]
+    cloud = synth.mountain_cloud(nx, ny, seed=args.seed + tile["seed_offset"], origin=origin)
     d_cloud = torch.from_numpy(cloud).to(dev)  # inputs resident in HBM before the timed region
     n_pts = cloud.shape[0]
-    start = [origin[0] + nx * 0.05, origin[1] + ny * 0.05, 0.0]
+    start = [tile["centre"][0], tile["centre"][1], 0.0]
     del cloud
 
     eng = trg_planner.Engine(**dict(MOUNTAIN, sample_num=S), device=local_rank)
@@ -131,12 +133,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        it = torch.tensor([items], dtype=torch.float64, device=dev)
-        dist.all_reduce(it, op=dist.ReduceOp.SUM)
-        items = float(it.item())
+        items, dt = tiling.reduce_throughput(items, dt, dist, dev)
 
     if rank == 0:
         st = eng.stats()
@@ -158,7 +155,8 @@ def main():
             "config": {
                 "workload": label, "points_per_gpu": n_pts, "V_prime": V, "E_prime": E,
                 "sampler": "counter-based table, seed 7, 16 bits",
-                "sharding": "one terrain tile per rank, no collective" if world > 1 else "single tile",
+                "sharding": (f"{tile['grid'][0]}x{tile['grid'][1]} terrain tiles, one per rank, "
+                             "no data-path collective") if world > 1 else "single tile",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,

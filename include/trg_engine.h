@@ -173,6 +173,10 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path);
  * max_points x 3 floats; info->num_points is the full length. */
 TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goal_xyz[3],
                           float *path_xyz, int32_t max_points, TrgPathInfo *info);
+/* reference: TRG::checkReadched (sic) trg.cpp:567-574 / TRG::checkReplan trg.cpp:576-601; 1 = true */
+int32_t trg_engine_check_reached(TrgEngine *e, const float pos_xy[2]);
+int32_t trg_engine_check_replan(TrgEngine *e, const float pos_xy[2], const float *path_xyz,
+                                int32_t n_path);
 /* reference: TRG::refinePath trg.cpp:692-730.  Returns the number of output points. */
 int32_t trg_engine_refine_path(const float *in_xyz, int32_t n_in, float *out_xyz, int32_t max_out);
 

@@ -1843,6 +1843,30 @@ TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goa
   return e->fail(TRG_ERR_NOT_FOUND, "no path");
 }
 
+// reference: TRG::checkReadched (sic) trg.cpp:567-574 and TRG::checkReplan trg.cpp:576-601
+int32_t trg_engine_check_reached(TrgEngine *e, const float pos_xy[2]) {
+  if (!e || !pos_xy) return 0;
+  const float dist = norm2f(e->goal_pose2d[0] - pos_xy[0], e->goal_pose2d[1] - pos_xy[1]);
+  return dist < e->prm.goal_tolerance ? 1 : 0;
+}
+
+int32_t trg_engine_check_replan(TrgEngine *e, const float pos_xy[2], const float *path_xyz,
+                                int32_t n_path) {
+  if (!e || !pos_xy) return 0;
+  if (e->goal_node < 0 || e->goal_node >= (int)e->nx.size()) return 0;
+  const int g = e->goal_node;
+  const float dist2subgoal = norm2f(e->nx[g] - pos_xy[0], e->ny[g] - pos_xy[1]);
+  if (!e->goal_known && dist2subgoal < e->prm.goal_tolerance) return 1;
+  if (!e->goal_known && e->nstate[g] != TRG_NODE_FRONTIER) return 1;
+  kd_sync(e);
+  std::vector<int> hits;
+  for (int i = 0; i < n_path; ++i) {
+    e->kd.range(path_xyz[3 * i], path_xyz[3 * i + 1], e->prm.robot_size, hits);
+    if (hits.empty()) return 1;
+  }
+  return 0;
+}
+
 int32_t trg_engine_refine_path(const float *in_xyz, int32_t n_in, float *out_xyz, int32_t max_out) {
   if (!in_xyz || n_in <= 0) return 0;
   // point_between == 1: p0,p1,p1,p2,p2,...  then a 3-tap mean, last point passed through

@@ -8,3 +8,4 @@ __version__ = "1.0.0"
 
 from ._engine import (Engine, CsrGraph, TrgError, build_library, load_library, LIB_PATH)  # noqa: F401
 from .api import TRG, Edge, Node, NodeState  # noqa: F401
+from .planner import TRGPlanner  # noqa: F401

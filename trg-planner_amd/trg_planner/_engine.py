@@ -78,6 +78,7 @@ EXPORTS = [
     "trg_engine_is_collision_batch", "trg_engine_nearest_z_batch", "trg_engine_edge_risk_batch",
     "trg_engine_is_frontier_batch", "trg_engine_get_stats", "trg_engine_get_sampler_table",
     "trg_engine_debug_map_index", "trg_engine_set_option", "trg_engine_fallback_reason",
+    "trg_engine_check_reached", "trg_engine_check_replan",
 ]
 
 
@@ -136,6 +137,10 @@ def load_library():
     L.trg_engine_get_stats.argtypes = [vp, C.POINTER(TrgStats)]
     L.trg_engine_get_sampler_table.argtypes = [vp, fp, fp]
     L.trg_engine_debug_map_index.argtypes = [vp, C.c_int, fp, fp, fp, ip, ip, fp]
+    L.trg_engine_check_reached.argtypes = [vp, fp]
+    L.trg_engine_check_reached.restype = C.c_int32
+    L.trg_engine_check_replan.argtypes = [vp, fp, fp, C.c_int32]
+    L.trg_engine_check_replan.restype = C.c_int32
     L.trg_engine_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.trg_engine_fallback_reason.argtypes = [vp]
     L.trg_engine_fallback_reason.restype = C.c_char_p
@@ -279,6 +284,15 @@ class Engine:
             return np.empty((0, 3), np.float32), info
         self._chk(st)
         return path[:info.num_points].copy(), info
+
+    def check_reached(self, pos2d):
+        p = np.ascontiguousarray(pos2d, dtype=np.float32)
+        return bool(self.L.trg_engine_check_reached(self.h, _f(p)))
+
+    def check_replan(self, pos2d, path):
+        p = np.ascontiguousarray(pos2d, dtype=np.float32)
+        path = np.ascontiguousarray(path, dtype=np.float32).reshape(-1, 3)
+        return bool(self.L.trg_engine_check_replan(self.h, _f(p), _f(path), path.shape[0]))
 
     def refine_path(self, path):
         path = np.ascontiguousarray(path, dtype=np.float32).reshape(-1, 3)

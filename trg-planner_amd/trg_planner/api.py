@@ -97,6 +97,12 @@ class TRG:
         path, info = self.engine.plan(start2d, goal_pose)
         return info.num_points > 0, path, info.direct_dist, info.path_length, info.avg_risk
 
+    def checkReadched(self, pos2d):  # (sic) the reference's spelling, trg.h:78
+        return self.engine.check_reached(pos2d)
+
+    def checkReplan(self, pos2d, path):
+        return self.engine.check_replan(pos2d, path)
+
     def refinePath(self, in_path):
         return self.engine.refine_path(in_path)
 
