@@ -173,7 +173,8 @@ def main():
                 "edge_evals_gpu": st["edge_evals_gpu"], "nn_ties": st["nn_ties"],
                 "gate_uncertain": st["gate_uncertain"], "bfs_levels": st["bfs_levels"],
                 "used_device_bfs": st["used_device_bfs"], "bfs_fallbacks": st["bfs_fallbacks"],
-                "bfs_max_spin": st["bfs_max_spin"],
+                "bfs_max_spin": st["bfs_max_spin"], "ms_bfs_loop": st["ms_bfs_loop"],
+                "ms_deferred": st["ms_deferred"], "ms_set_map_total": st["ms_set_map_total"],
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -129,6 +129,8 @@ typedef struct TrgStats {
   uint64_t used_device_bfs;    /* 1: BFS + CSR ran on the GPU; 0: host replay */
   uint64_t bfs_fallbacks;      /* device path declined and the host replay redid the build */
   uint64_t bfs_max_spin;       /* longest dependency wait (poll iterations) in k_bfs_resolve */
+  double ms_bfs_loop;          /* device path: wall time of the level loop */
+  double ms_deferred;          /* device path: wall time of the deferred edge evaluations */
 } TrgStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

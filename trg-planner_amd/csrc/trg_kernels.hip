@@ -753,8 +753,146 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
   const int T = stage_tile(m, box, tile);
 
   unsigned long long hits = 0;
-  // segment walk, trg.cpp:282-288 (float accumulation of i is part of the semantics)
   const float ds = p.robot_size * 0.5f;
+
+  // Fast path: ONE sweep over the staged tile serves every segment-walk disc and the ellipse
+  // gather; the per-disc statistics (count, z-min, z-max) are reduced with interleaved butterflies
+  // and then examined in walk order, so the early exit on the first colliding disc -- and the hit
+  // count the reference would have produced up to it -- are unchanged.
+  constexpr int KMAX = 8;
+  if (T >= 0 && ds > 0.0f) {
+    float qx[KMAX], qy[KMAX];
+    int K = 0;
+    bool fits = true;
+    for (float i = 0; i < g.dist; i += ds) {  // trg.cpp:283 (float accumulation is semantics)
+      if (K == KMAX) {
+        fits = false;
+        break;
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k == K) {
+          qx[k] = x1 + i * g.dirx;
+          qy[k] = y1 + i * g.diry;
+        }
+      ++K;
+    }
+    if (fits) {
+      const float r2 = p.robot_size * p.robot_size;
+      int cnt[KMAX];
+      float zmn[KMAX], zmx[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        cnt[k] = 0;
+        zmn[k] = FLT_MAX;
+        zmx[k] = -FLT_MAX;
+      }
+      Moments mo;
+      for (int i = lane; i < T; i += WAVE) {
+        const float px = tile.x[i], py = tile.y[i], pz = tile.z[i];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < K) {
+            const float dx = px - qx[k];
+            const float dy = py - qy[k];
+            const float d2 = dx * dx + dy * dy;
+            if (d2 <= r2) {
+              cnt[k]++;
+              zmn[k] = fminf(zmn[k], pz);
+              zmx[k] = fmaxf(zmx[k], pz);
+            }
+          }
+        }
+        ellipse_point(ep, px, py, pz, mo);
+      }
+#pragma unroll
+      for (int msk = 32; msk >= 1; msk >>= 1) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < K) {
+            cnt[k] += __shfl_xor(cnt[k], msk);
+            zmn[k] = fminf(zmn[k], __shfl_xor(zmn[k], msk));
+            zmx[k] = fmaxf(zmx[k], __shfl_xor(zmx[k], msk));
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const int n = cnt[k];
+          hits += (unsigned long long)n;
+          bool col;
+          if (n == 0) {
+            col = true;  // trg.cpp:749-752
+          } else {
+            int bad = 0;
+            // every |z - z_med| <= zmax - zmin (rounding is monotone): a flat disc needs no median
+            if (!(zmx[k] - zmn[k] <= p.height_threshold)) {
+              int nn = 0;
+              for (int base = 0; base < T; base += WAVE) {
+                const int i = base + lane;
+                bool hit = false;
+                float z = 0.0f;
+                if (i < T) {
+                  const float dx = tile.x[i] - qx[k];
+                  const float dy = tile.y[i] - qy[k];
+                  z = tile.z[i];
+                  hit = dx * dx + dy * dy <= r2;
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (hit) tile.zb[nn + __popcll(mask & lanemask_lt())] = z;
+                nn += __popcll(mask);
+              }
+              wave_lds_sync();
+              bad = median_count(tile.zb, n, p.height_threshold);
+              wave_lds_sync();
+            }
+            col = (float)bad / (float)n > p.collision_threshold;
+          }
+          if (col) {
+            o.status = EDGE_SEG | g.uncertain;
+            o.hits = (int)hits;
+            return o;
+          }
+        }
+      }
+      // interleaved butterflies for the ellipse moments
+      int in_range = mo.in_range, kept = mo.kept;
+      double sm[9] = {mo.s_x, mo.s_y, mo.s_z, mo.s_xx, mo.s_xy, mo.s_xz, mo.s_yy, mo.s_yz, mo.s_zz};
+#pragma unroll
+      for (int msk = 32; msk >= 1; msk >>= 1) {
+        in_range += __shfl_xor(in_range, msk);
+        kept += __shfl_xor(kept, msk);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) sm[q] += __shfl_xor(sm[q], msk);
+      }
+      hits += (unsigned long long)in_range;
+      o.hits = (int)hits;
+      o.n_pts = kept;
+      if (in_range == 0) {
+        o.status = EDGE_EMPTY | g.uncertain;
+        return o;
+      }
+      if (kept < 3) {
+        o.status = EDGE_FEW | g.uncertain;
+        return o;
+      }
+      const double n = (double)kept;
+      const double mx = sm[0] / n, my = sm[1] / n, mz = sm[2] / n;
+      const double inv = 1.0 / (double)(kept - 1);
+      o.c[0] = (float)((sm[3] - n * mx * mx) * inv);
+      o.c[1] = (float)((sm[4] - n * mx * my) * inv);
+      o.c[2] = (float)((sm[5] - n * mx * mz) * inv);
+      o.c[3] = (float)((sm[6] - n * my * my) * inv);
+      o.c[4] = (float)((sm[7] - n * my * mz) * inv);
+      o.c[5] = (float)((sm[8] - n * mz * mz) * inv);
+      o.status = EDGE_OK | g.uncertain;
+      return o;
+    }
+  }
+
+  // general path: one disc at a time (long edges, oversized boxes, dense maps)
+  // segment walk, trg.cpp:282-288 (float accumulation of i is part of the semantics)
   int guard = 0;
   for (float i = 0; i < g.dist; i += ds) {
     const float qx = x1 + i * g.dirx;

@@ -65,7 +65,7 @@ class TrgStats(C.Structure):
         ("ms_init_graph_total", C.c_double), ("ms_replay_host", C.c_double),
         ("ms_finalize_host", C.c_double), ("ms_wait_gpu", C.c_double),
         ("bfs_levels", C.c_uint64), ("used_device_bfs", C.c_uint64), ("bfs_fallbacks", C.c_uint64),
-        ("bfs_max_spin", C.c_uint64)]
+        ("bfs_max_spin", C.c_uint64), ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
