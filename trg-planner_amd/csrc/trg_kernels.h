@@ -94,8 +94,8 @@ void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, i
                        DeviceCounters *ctr, hipStream_t s);
 
 // ---- device-resident BFS (trg_bfs.inc) ------------------------------------------------------------
-constexpr int BFS_NBMAX = 32;      // pool entries per sample slot (static segments + overflow)
-constexpr int BFS_NB_STATIC = 16;  // list length served from a candidate's own fixed segment
+constexpr int BFS_NBMAX = 40;      // pool entries per sample slot (static segments + overflow)
+constexpr int BFS_NB_STATIC = 24;  // list length served from a candidate's own fixed segment
 constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, nodes are >= robot_size apart)
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
@@ -114,6 +114,7 @@ struct BfsDev {
   int *nstate;
   int vcap;
   int *gcnt, *gslots;
+  float *gsx, *gsy;  // positions of the nodes in gslots (saves a dependent load per probe)
   float gx0, gy0, ginv, gcell;
   int GW, GH;
   // frontier ping-pong
@@ -134,7 +135,8 @@ struct BfsDev {
   int *unc_list;
   float *unc_rec;
   // candidate hash of the level
-  int *ht_key, *ht_val;
+  int *ht_key, *ht_val, *ht_slot;
+  float *ht_x, *ht_y;
   int ht_size;
   // call log (one record per sample slot, in program order)
   int *call_n1, *call_n2, *call_status;
