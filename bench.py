@@ -43,7 +43,7 @@ def cpu_baseline(sample_num, seconds_hint=20.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_api as oa
     from trg_planner import synth
-    nx = ny = 700  # 490 k points, ~32 k nodes at S=16: about 10-20 s of single-core work
+    nx = ny = 1200  # 1.44 M points, ~94 k nodes at S=16: about 10-25 s of single-core work
     cloud = synth.mountain_cloud(nx, ny, seed=20250418)
     used_ref = oa.use_reference_kd(True)
     prm = dict(MOUNTAIN, sample_num=sample_num)
@@ -137,16 +137,29 @@ def main():
 
     if rank == 0:
         st = eng.stats()
+        # the three map-query kernels (the rest of the build is index/graph bookkeeping); names are
+        # those rocprofv3 shows for the path that ran
+        dev = st["used_device_bfs"] == 1
         kernels = {
-            "k_edges": (acc["bytes_edge_kernel"], acc["ms_edge_kernel"], acc["launches_edge_kernel"]),
-            "k_spec_edges": (acc["bytes_spec_kernel"], acc["ms_spec_kernel"],
-                             acc["launches_spec_kernel"]),
+            ("k_calls_gather" if dev else "k_edges"):
+                (acc["bytes_edge_kernel"], acc["ms_edge_kernel"], acc["launches_edge_kernel"]),
+            ("k_bfs_spec" if dev else "k_spec_edges"):
+                (acc["bytes_spec_kernel"], acc["ms_spec_kernel"], acc["launches_spec_kernel"]),
             "k_sample_nodes": (acc["bytes_sample_kernel"], acc["ms_sample_kernel"],
                                acc["launches_sample_kernel"]),
         }
         dom = max(kernels, key=lambda k: kernels[k][1])
         b, ms, launches = kernels[dom]
         achieved = (b / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        # HBM bytes per launch from the separate rocprofv3 --pmc passes of the same workload
+        # (profiles/, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"r01_{args.workload}_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if dom in tj:
+                traffic = tj[dom]["hbm_bytes_per_dispatch"]
+                traffic_src = os.path.relpath(tpath, ROOT)
         out = {
             "metric": "TRG nodes+edges built/sec", "value": items / dt, "unit": "nodes+edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,9 +173,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "alg_bytes_per_launch": b / max(1, launches),
                 "avg_launch_ms": ms / max(1, launches), "launches": launches,
+                "all_kernels_GBps": {k: ((v[0] / 1e9) / (v[1] / 1e3) if v[1] > 0 else 0.0)
+                                     for k, v in kernels.items()},
             },
             "breakdown_last_step": {
                 "ms_index_build_gpu": st["ms_index_build"], "ms_init_graph_total": st["ms_init_graph_total"],

@@ -33,6 +33,7 @@ if st:
                   f"{float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | "
                   f"{float(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
     print()
+traffic = {}
 for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     cc = find(sub, "*counter_collection.csv")
     if not cc:
@@ -53,4 +54,24 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for k in sorted(tot, key=lambda k: -tot[k]):
         print(f"| {k} | {calls[k]} | {tot[k]:.0f} | {tot[k] * 1024 / 1e6:.2f} | "
               f"{tot[k] * 1024 / 1e3 / max(1, calls[k]):.1f} |")
+        traffic.setdefault(k, {})[ctr] = {"dispatches": calls[k], "raw_kib_total": tot[k]}
     print()
+if traffic:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+    # exactly half of the bytes of a coalesced streaming read (calibrated here on k_bounds /
+    # k_cell_count, whose reads are exactly 12 B/point), WRITE_SIZE reads bytes as they are.
+    import json
+    out_j = {}
+    for k, v in traffic.items():
+        f = v.get("FETCH_SIZE", {"dispatches": 0, "raw_kib_total": 0.0})
+        w = v.get("WRITE_SIZE", {"dispatches": 0, "raw_kib_total": 0.0})
+        n = max(1, f["dispatches"] or w["dispatches"])
+        out_j[k] = {
+            "dispatches": n,
+            "fetch_bytes_per_dispatch_corrected": 2.0 * f["raw_kib_total"] * 1024 / n,
+            "write_bytes_per_dispatch": w["raw_kib_total"] * 1024 / n,
+        }
+        out_j[k]["hbm_bytes_per_dispatch"] = (out_j[k]["fetch_bytes_per_dispatch_corrected"] +
+                                              out_j[k]["write_bytes_per_dispatch"])
+    with open(os.path.join(out, "traffic.json"), "w") as fjs:
+        json.dump(out_j, fjs, indent=1, sort_keys=True)

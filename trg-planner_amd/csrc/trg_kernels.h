@@ -163,7 +163,8 @@ void launch_bfs_sample(const MapView &m, QueryParams p, const float *cos_t, cons
 // classify + candidate scan/fill + speculative parent edges (ends where the host must look at
 // BFS_CTR_NUNC); flag / scan_tmp: scratch of count*S+1 and count*S/2048+4 ints
 void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int count, int *flag,
-                        int *scan_tmp, DeviceCounters *ctr, hipStream_t s);
+                        int *scan_tmp, DeviceCounters *ctr, hipStream_t s, hipEvent_t spec_begin,
+                        hipEvent_t spec_end);
 // neighbour lists + resolve + call emission
 constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-resident (<= 512 groups)
 void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
