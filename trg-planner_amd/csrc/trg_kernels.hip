@@ -120,7 +120,7 @@ __device__ float select_kth_global(const MapView &m, const CellRange &c, float q
 // operation order (kdtree.c:277-281), then the isCollision statistics (trg.cpp:763-772).
 template <bool NN>
 __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float h, float *zbuf,
-                           DeviceCounters *ctr) {
+                           DeviceCounters *ctr, int cap = HCAP) {
   const int lane = lane_id();
   const float r2 = r * r;
   const CellRange c = cells_for(m, qx, qy, r);
@@ -144,7 +144,7 @@ __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float 
       const unsigned long long mask = __ballot(hit);
       if (hit) {
         const int pos = n + __popcll(mask & lanemask_lt());
-        if (pos < HCAP) zbuf[pos] = z;
+        if (pos < cap) zbuf[pos] = z;
         if (NN) {
           const int pm = m.perm[i];
           if (d2 < best_d2 || (d2 == best_d2 && pm < best_perm)) {
@@ -186,7 +186,7 @@ __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float 
 
   float zmed;
   const int k = n / 2;  // pts[pts.size() / 2] after the ascending sort (trg.cpp:764)
-  if (n <= HCAP) {
+  if (n <= cap) {
     wave_lds_sync();
     float mine = 0.0f;
     bool found = false;
@@ -559,8 +559,8 @@ __device__ __forceinline__ void ellipse_point(const EllipseParams &ep, float px,
 // small box.  The wave loads the candidate points of that box ONCE -- every row segment is a
 // contiguous range, all loads are issued back to back -- into a per-wave LDS tile, and every
 // query then scans the tile instead of going back to global memory.
-constexpr int TCAP = 512;            // points per tile (x, y, z) and entries of the hit buffer
-constexpr int TITER = TCAP / WAVE;   // 8
+constexpr int TCAP = 320;            // points per tile (x, y, z) and entries of the hit buffer
+constexpr int TITER = TCAP / WAVE;   // 5
 constexpr int MAXROWS = 32;
 
 struct Tile {
@@ -759,7 +759,7 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
   // gather; the per-disc statistics (count, z-min, z-max) are reduced with interleaved butterflies
   // and then examined in walk order, so the early exit on the first colliding disc -- and the hit
   // count the reference would have produced up to it -- are unchanged.
-  constexpr int KMAX = 8;
+  constexpr int KMAX = 6;  // dist <= expand_dist + robot_size on every edge the build tries
   if (T >= 0 && ds > 0.0f) {
     float qx[KMAX], qy[KMAX];
     int K = 0;
@@ -787,7 +787,6 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
         zmn[k] = FLT_MAX;
         zmx[k] = -FLT_MAX;
       }
-      Moments mo;
       for (int i = lane; i < T; i += WAVE) {
         const float px = tile.x[i], py = tile.y[i], pz = tile.z[i];
 #pragma unroll
@@ -803,7 +802,6 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
             }
           }
         }
-        ellipse_point(ep, px, py, pz, mo);
       }
 #pragma unroll
       for (int msk = 32; msk >= 1; msk >>= 1) {
@@ -856,7 +854,10 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
           }
         }
       }
-      // interleaved butterflies for the ellipse moments
+      // second sweep: ellipse gather (kept apart from the disc sweep to bound register pressure),
+      // then interleaved butterflies for its moments
+      Moments mo;
+      for (int i = lane; i < T; i += WAVE) ellipse_point(ep, tile.x[i], tile.y[i], tile.z[i], mo);
       int in_range = mo.in_range, kept = mo.kept;
       double sm[9] = {mo.s_x, mo.s_y, mo.s_z, mo.s_xx, mo.s_xy, mo.s_xz, mo.s_yy, mo.s_yz, mo.s_zz};
 #pragma unroll
@@ -903,7 +904,8 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
       col = tile_disc_collides(tile, T, qx, qy, p.robot_size, p.height_threshold,
                                p.collision_threshold, n);
     } else {
-      const Disc d = disc_query<false>(m, qx, qy, p.robot_size, p.height_threshold, zbuf_big, ctr);
+      const Disc d =
+          disc_query<false>(m, qx, qy, p.robot_size, p.height_threshold, zbuf_big, ctr, TCAP);
       n = d.n;
       col = disc_collides(d, p.collision_threshold);
     }
@@ -1197,12 +1199,13 @@ __global__ __launch_bounds__(QW *WAVE) void k_probe_nearest_z(MapView m, QueryPa
 
 // LDS per wave of the edge kernels: x, y, z tile + hit buffer (4 * TCAP floats = 8 KB); the hit
 // buffer doubles as the scratch of the global-memory fallback, whose capacity is therefore TCAP.
-static_assert(HCAP >= TCAP, "fallback hit buffer");
+static_assert(TCAP % WAVE == 0, "tile capacity is a whole number of wave sweeps");
+constexpr int EDGE_WAVES_PER_SIMD = 6;  // register budget of the edge kernels (<= 80 VGPRs); 5 and 8 measured slower
 struct EdgeLds {
-  float x[QW][TCAP], y[QW][TCAP], z[QW][TCAP], zb[QW][HCAP];
+  float x[QW][TCAP], y[QW][TCAP], z[QW][TCAP], zb[QW][TCAP];
 };
 
-__global__ __launch_bounds__(QW *WAVE) void k_edges(MapView m, QueryParams p, const float *p1,
+__global__ __launch_bounds__(QW *WAVE, EDGE_WAVES_PER_SIMD) void k_edges(MapView m, QueryParams p, const float *p1,
                                                     const float *p2, int count, float *mid,
                                                     DeviceCounters *ctr) {
   __shared__ EdgeLds lds;
@@ -1219,7 +1222,7 @@ __global__ __launch_bounds__(QW *WAVE) void k_edges(MapView m, QueryParams p, co
   store_mid(mid, q, o);
 }
 
-__global__ __launch_bounds__(QW *WAVE) void k_spec_edges(MapView m, QueryParams p,
+__global__ __launch_bounds__(QW *WAVE, EDGE_WAVES_PER_SIMD) void k_spec_edges(MapView m, QueryParams p,
                                                          const float *node_xyz, int count,
                                                          const int *n_acc, const float *sx,
                                                          const float *sy, const float *sz,
