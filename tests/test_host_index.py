@@ -13,3 +13,13 @@ def test_host_indices_match_kd_semantics(oa, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("ok")
+
+
+def test_map_order_replica_matches_libstdcxx(tmp_path):
+    """cleanGraph's renumbering follows std::unordered_map iteration order; the engine's O(n)
+    replica of that order (map_order_sim.h) must match the real container, bucket counts included."""
+    exe = tmp_path / "map_order_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17",
+                           os.path.join(ROOT, "tests", "cpp", "map_order_check.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr

@@ -31,6 +31,7 @@
 
 #include "../../include/trg_engine.h"
 #include "host_index.h"
+#include "map_order_sim.h"
 #include "trg_kernels.h"
 
 namespace {
@@ -109,10 +110,86 @@ struct EdgePool {
   }
 };
 
+// Minimal vector over pinned host memory (hipHostMalloc): the CSR the engine hands out is the
+// destination of the final device-to-host copies, which run at full PCIe rate only into pinned
+// pages; no value-initialisation on resize (an 80 MB memset would cost as much as the copy).
+template <typename T>
+struct PVec {
+  T *p = nullptr;
+  size_t n = 0, cap = 0;
+  bool pinned = false;
+  PVec() = default;
+  PVec(const PVec &) = delete;
+  PVec &operator=(const PVec &o) {
+    resize(o.n);
+    if (o.n) memcpy(p, o.p, o.n * sizeof(T));
+    return *this;
+  }
+  PVec &operator=(const std::vector<T> &o) {
+    resize(o.size());
+    if (!o.empty()) memcpy(p, o.data(), o.size() * sizeof(T));
+    return *this;
+  }
+  ~PVec() { release(); }
+  void release() {
+    if (p) {
+      if (pinned) (void)hipHostFree(p);
+      else free(p);
+    }
+    p = nullptr;
+    n = cap = 0;
+  }
+  void reserve(size_t m) {
+    if (m <= cap) return;
+    size_t nc = std::max(m, cap + cap / 2);
+    T *np = nullptr;
+    bool pin = hipHostMalloc((void **)&np, nc * sizeof(T), hipHostMallocDefault) == hipSuccess;
+    if (!pin) np = (T *)malloc(nc * sizeof(T));
+    if (n) memcpy(np, p, n * sizeof(T));
+    if (p) {
+      if (pinned) (void)hipHostFree(p);
+      else free(p);
+    }
+    p = np;
+    cap = nc;
+    pinned = pin;
+  }
+  void resize(size_t m) {
+    reserve(m);
+    n = m;
+  }
+  void assign(size_t m, const T &v) {
+    resize(m);
+    for (size_t i = 0; i < m; ++i) p[i] = v;
+  }
+  void clear() { n = 0; }
+  bool empty() const { return n == 0; }
+  size_t size() const { return n; }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  T *begin() { return p; }
+  T *end() { return p + n; }
+  const T *begin() const { return p; }
+  const T *end() const { return p + n; }
+  void push_back(const T &v) {
+    if (n == cap) reserve(std::max<size_t>(16, cap * 2));
+    p[n++] = v;
+  }
+  template <typename It>
+  void append(It first, It last) {
+    const size_t m = (size_t)(last - first);
+    reserve(n + m);
+    for (size_t i = 0; i < m; ++i) p[n + i] = first[i];
+    n += m;
+  }
+};
+
 struct Csr {
-  std::vector<float> xyz;
-  std::vector<int32_t> state, rowptr, col, cid;
-  std::vector<float> w, dist;
+  PVec<float> xyz;
+  PVec<int32_t> state, rowptr, col, cid;
+  PVec<float> w, dist;
   void clear() {
     xyz.clear();
     state.clear();
@@ -202,6 +279,10 @@ struct TrgEngine {
   std::vector<int> nstate;
   std::vector<int> ncid;  // creation index inside the last build
   std::unordered_map<int, int> order_map;  // mirrors trgStruct::nodes (iteration order only)
+  // After a device build the container history is carried by an O(n) replica of the hashtable's
+  // iteration order (map_order_sim.h); the real map is rebuilt from it only if a host path needs it.
+  MapOrderSim nodes_sim;
+  bool real_map_stale = false;
   EdgePool edges;
   int node_id = 0;
   float root_pos[2] = {0, 0};
@@ -238,6 +319,7 @@ struct TrgEngine {
   bool use_device_bfs = true;    // device-resident BFS when expandGraph's step 3 is disabled
   bool pool_valid = true;        // e->edges mirrors csr_global
   bool host_grid_valid = true;   // e->grid holds the current node set
+  bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
   TrgStats stats{};
@@ -636,8 +718,30 @@ void reset_graph_global(TrgEngine *e) {
   e->node_id = 0;
   e->kd.clear();
   e->kd_valid = true;  // empty tree is trivially in sync
+  e->kd_order_dirty = false;
   e->kd_insert_order.clear();
   e->goal_node = -1;
+}
+
+// the node map's keys in iteration order, whichever representation is current
+void node_map_order(const TrgEngine *e, std::vector<int> &out) {
+  if (e->real_map_stale) {
+    e->nodes_sim.iteration_order(out);
+  } else {
+    out.clear();
+    out.reserve(e->order_map.size());
+    for (auto &kv : e->order_map) out.push_back(kv.first);
+  }
+}
+// rebuild the real container exactly as cleanGraph left it: new_nodes[new_id] for the dense new ids,
+// then nodes = new_nodes (trg.cpp:502, 526)
+void ensure_real_map(TrgEngine *e) {
+  if (!e->real_map_stale) return;
+  std::unordered_map<int, int> fresh;
+  const int n = (int)e->nodes_sim.size();
+  for (int k = 0; k < n; ++k) fresh[k] = k;
+  e->order_map = std::move(fresh);
+  e->real_map_stale = false;
 }
 
 void grid_rebuild(TrgEngine *e) {
@@ -659,7 +763,17 @@ void grid_rebuild(TrgEngine *e) {
 
 // bring the reference-shaped kd replica in sync with the node set (lazy: the replay only needs it
 // for ties and for step 3; queries need it for hit order)
+// after a device build the node-tree refill order (the node map's iteration order, trg.cpp:528-530)
+// is derived on demand
+void materialize_kd_order(TrgEngine *e) {
+  if (!e->kd_order_dirty) return;
+  node_map_order(e, e->kd_insert_order);
+  e->kd_order_dirty = false;
+  e->kd_valid = false;
+}
+
 void kd_sync(TrgEngine *e) {
+  materialize_kd_order(e);
   if (!e->kd_valid) {
     e->kd.clear();
     e->kd_valid = true;
@@ -1112,6 +1226,7 @@ void clean_graph(TrgEngine *e) {
   e->order_map = new_nodes;
   e->kd_insert_order.clear();
   for (auto &kv : e->order_map) e->kd_insert_order.push_back(kv.first);
+  e->kd_order_dirty = false;
   e->kd_valid = false;
   grid_rebuild(e);
   e->host_grid_valid = true;
@@ -1162,8 +1277,9 @@ TrgStatus set_local_graph(TrgEngine *e) {
     if (st != TRG_OK) return st;
   }
   e->local_map.clear();  // resetGraph("local"): clear() keeps the bucket array, as the reference's does
-  for (auto &kv : e->order_map) {
-    const int id = kv.first;
+  std::vector<int> global_order;
+  node_map_order(e, global_order);
+  for (int id : global_order) {
     if (n[id] == 0) continue;
     e->local_map[id] = id;
     e->lkd.insert(e->nx[id], e->ny[id], id);
@@ -1338,6 +1454,7 @@ TrgStatus trg_engine_reset_graph(TrgEngine *e, TrgKind kind) {
     e->local_map.clear();
     e->lkd.clear();
   } else {
+    ensure_real_map(e);
     reset_graph_global(e);
     e->csr_global.clear();
   }
@@ -1361,7 +1478,16 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     e->stats.ms_set_map_total = keep.ms_set_map_total;
   }
   HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
+  const bool want_device = !e->step3 && e->use_device_bfs;
+  if (!want_device) ensure_real_map(e);
+  MapOrderSim sim_before;  // container history as of before this build (for the fallback)
+  if (want_device) {
+    if (!e->real_map_stale) e->nodes_sim.adopt_bucket_state(e->order_map);
+    sim_before = e->nodes_sim;
+  }
+  const bool stale_before = e->real_map_stale;
   reset_graph_global(e);
+  e->real_map_stale = stale_before;
   e->pool_valid = true;
   e->epoch = 0;
   e->calls.clear();
@@ -1405,6 +1531,9 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     // reference kd-tree's shape): redo the build with the host replay, which handles those
     e->stats.bfs_fallbacks++;
     HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
+    e->nodes_sim = sim_before;
+    e->real_map_stale = stale_before;
+    ensure_real_map(e);
     reset_graph_global(e);
   }
 
@@ -1452,8 +1581,10 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   TrgStatus st = ensure_sampler(e, nullptr);
   if (st != TRG_OK) return st;
   e->epoch++;
+  ensure_real_map(e);
   ensure_pool(e);
   ensure_host_grid(e);
+  materialize_kd_order(e);  // nodes created below are appended to the existing insertion order
   e->calls.clear();
   e->pending_calls.clear();
 
@@ -1524,7 +1655,7 @@ TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out) {
     c->clear();
     c->rowptr.push_back(0);
     for (int id : e->local_nodes) {
-      c->xyz.insert(c->xyz.end(), full.xyz.begin() + 3 * id, full.xyz.begin() + 3 * id + 3);
+      c->xyz.append(full.xyz.begin() + 3 * id, full.xyz.begin() + 3 * id + 3);
       c->state.push_back(full.state[id]);
       c->cid.push_back(id);  // for the local view: the node's global id
       for (int k = full.rowptr[id]; k < full.rowptr[id + 1]; ++k) {
@@ -1565,8 +1696,9 @@ TrgStatus trg_engine_save_json(TrgEngine *e, const char *path) {
   f << "{\n    \"edges\": [";
   // nodes/edges are listed in the node map's iteration order, like the reference
   bool first = true;
-  for (auto &kv : e->order_map) {
-    const int id = kv.first;
+  std::vector<int> map_order;
+  node_map_order(e, map_order);
+  for (int id : map_order) {
     for (int ed = e->edges.head[id]; ed >= 0; ed = e->edges.next[ed]) {
       snprintf(buf, sizeof(buf),
                "%s\n        {\n            \"dist\": %.9g,\n            \"source\": %d,\n"
@@ -1579,8 +1711,7 @@ TrgStatus trg_engine_save_json(TrgEngine *e, const char *path) {
   }
   f << (first ? "]" : "\n    ]") << ",\n    \"nodes\": [";
   first = true;
-  for (auto &kv : e->order_map) {
-    const int id = kv.first;
+  for (int id : map_order) {
     snprintf(buf, sizeof(buf),
              "%s\n        {\n            \"id\": %d,\n            \"pos\": [\n                %.9g,\n"
              "                %.9g,\n                %.9g\n            ],\n            \"state\": %d\n"
@@ -1695,6 +1826,7 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
     if (!c.eat(',')) break;
   }
   // loadPrebuiltGraph (trg.cpp:78-120): ids must be dense for the slot == id layout
+  ensure_real_map(e);
   int max_id = -1;
   for (auto &n : nodes) max_id = std::max(max_id, n.id);
   if (max_id + 1 != (int)nodes.size())
@@ -1747,8 +1879,9 @@ TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goa
   e->kd.range(goal_xyz[0], goal_xyz[1], e->prm.robot_size, hits);
   if (hits.empty()) {
     float min_dist = std::numeric_limits<float>::max();
-    for (auto &kv : e->order_map) {
-      const int id = kv.first;
+    std::vector<int> map_order;
+    node_map_order(e, map_order);
+    for (int id : map_order) {
       const float d = norm2f(e->nx[id] - goal_xyz[0], e->ny[id] - goal_xyz[1]);
       if (d < min_dist) {
         min_dist = d;
