@@ -10,9 +10,10 @@ summed over all ranks.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, every rank builds the graph of its own terrain tile (spatial-tile
-sharding, no data-path collective; weak scaling).  torch / RCCL are used for the barrier and the
-max-over-ranks reduction only.
+N > 1: one process per GPU, rank == spatial tile of one continuous terrain (weak scaling: every
+rank holds a C3-sized core + halo).  Each rank builds the graph of its core on its GPU; the
+tile-boundary edges are then stitched with two all-gather-v exchanges over RCCL
+(trg_planner/tiled.py; rule and parity oracle: DESIGN.md section 7).
 """
 import argparse
 import json
@@ -92,24 +93,44 @@ def main():
     import trg_planner
     from trg_planner import synth
 
-    from trg_planner import tiling
+    from trg_planner import tiled, tiling
     nx, ny, S, label = WORKLOADS[args.workload]
-    # spatial tile of this rank (C4/C5-style tiling: 2x1, 2x2, 4x2 ...): same generator, seed + rank
-    tile = tiling.tile_of_rank(rank, world, nx, ny)
-    origin = tile["origin"]
-    cloud = synth.mountain_cloud(nx, ny, seed=args.seed + tile["seed_offset"], origin=origin)
+    # One continuous terrain cut into a cols x rows grid of nx x ny tiles (C4/C5-style: 2x1, 2x2,
+    # 4x2 ...); rank == tile.  Every rank holds its core plus a 1.1 m halo and
+    # builds the graph of its core; for N > 1 the tile-boundary edges are stitched with two
+    # all-gather-v exchanges over RCCL (trg_planner/tiled.py).  N = 1 is the plain single-root build.
+    cols, rows = tiling.tile_layout(world)
+    halo_pts = 11 if world > 1 else 0
+    core = tiled.tile_cores(cols, rows, nx, ny)[rank]
+    win = tiled.tile_lattice_window(rank, cols, rows, nx, ny, halo_pts)
+    cloud = synth.mountain_tile(*win, seed=args.seed)
     d_cloud = torch.from_numpy(cloud).to(dev)  # inputs resident in HBM before the timed region
     n_pts = cloud.shape[0]
-    start = [tile["centre"][0], tile["centre"][1], 0.0]
+    start = [0.5 * float(core[0] + core[2]), 0.5 * float(core[1] + core[3]), 0.0]
     del cloud
 
     eng = trg_planner.Engine(**dict(MOUNTAIN, sample_num=S), device=local_rank)
     eng.set_sampler(7, 16)
+    if world > 1:
+        eng.set_tile(core, epoch=rank)
+    stitch_info = {"cross_edges": 0, "boundary_records": 0}
 
     def step():
         eng.set_global_map_device(d_cloud.data_ptr(), n_pts, 3)
         eng.init_graph(start)
-        return eng.graph_sizes("global")
+        V, E = eng.graph_sizes("global")
+        if world > 1:
+            class _G:  # node positions only: the stitch needs nothing else of the tile graph
+                pass
+            g = _G()
+            g.xyz = eng.node_xyz("global")
+            (ids, _, _), nrec = tiled.stitch(rank, g, core, cols, rows, MOUNTAIN["expand_dist"],
+                                             eng.edge_risk, dist, dev)
+            mine = int(((ids[:, 0] == rank).sum() + (ids[:, 2] == rank).sum())) if ids.size else 0
+            stitch_info["cross_edges"] = int(ids.shape[0])
+            stitch_info["boundary_records"] = nrec
+            E += mine  # directed cross edges that end up in this tile's adjacency lists
+        return V, E
 
     def fence():
         torch.cuda.synchronize()
@@ -168,8 +189,11 @@ def main():
             "config": {
                 "workload": label, "points_per_gpu": n_pts, "V_prime": V, "E_prime": E,
                 "sampler": "counter-based table, seed 7, 16 bits",
-                "sharding": (f"{tile['grid'][0]}x{tile['grid'][1]} terrain tiles, one per rank, "
-                             "no data-path collective") if world > 1 else "single tile",
+                "sharding": (f"{cols}x{rows} tiles of one continuous terrain, one per rank, core + "
+                             f"1.1 m halo; boundary edges stitched by 2 all-gather-v over RCCL "
+                             f"({stitch_info['cross_edges']} cross edges, "
+                             f"{stitch_info['boundary_records']} boundary records)")
+                if world > 1 else "single tile",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -186,9 +210,10 @@ def main():
                 "ms_wait_gpu": st["ms_wait_gpu"], "ms_sample_kernel": st["ms_sample_kernel"],
                 "ms_spec_kernel": st["ms_spec_kernel"], "ms_edge_kernel": st["ms_edge_kernel"],
                 "expanded_nodes": st["expanded_nodes"], "samples": st["samples"],
-                "edge_evals_gpu": st["edge_evals_gpu"], "nn_ties": st["nn_ties"],
+                "edge_evals_gpu": st["edge_evals_gpu"], "nn_ties": st["nn_ties"], "map_nn_ties": st["map_nn_ties"],
                 "gate_uncertain": st["gate_uncertain"], "bfs_levels": st["bfs_levels"],
                 "used_device_bfs": st["used_device_bfs"], "bfs_fallbacks": st["bfs_fallbacks"],
+                "bfs_host_levels": st["bfs_host_levels"],
                 "bfs_max_spin": st["bfs_max_spin"], "ms_bfs_loop": st["ms_bfs_loop"],
                 "ms_deferred": st["ms_deferred"], "ms_set_map_total": st["ms_set_map_total"],
             },

@@ -103,7 +103,8 @@ typedef struct TrgStats {
   uint64_t invalid_nodes;
   uint64_t edge_calls;         /* wireEdge() calls replayed */
   uint64_t edge_evals_gpu;     /* edge evaluations executed on the GPU (speculative ones included) */
-  uint64_t nn_ties;            /* fp32 distance ties seen by nearest-neighbour queries */
+  uint64_t nn_ties;            /* exact fp32 distance ties between nearest-NODE candidates; resolved
+                                  exactly (reference kd-tree traversal order, host_index.h) */
   uint64_t gate_uncertain;     /* slope gates decided by host libm atan2f */
   uint64_t sync_batches;       /* synchronous GPU round trips forced by the replay */
   /* bytes of map points inside query radii that the GPU kernels touched (12 B per hit) */
@@ -129,6 +130,11 @@ typedef struct TrgStats {
   uint64_t used_device_bfs;    /* 1: BFS + CSR ran on the GPU; 0: host replay */
   uint64_t bfs_fallbacks;      /* device path declined and the host replay redid the build */
   uint64_t bfs_max_spin;       /* longest dependency wait (poll iterations) in k_bfs_resolve */
+  uint64_t bfs_host_levels;    /* BFS levels replayed on the host because of an exact distance tie */
+  uint64_t map_nn_ties;        /* elevation lookups (trg.cpp:244-247) whose two nearest MAP points are at
+                                  exactly the same fp32 distance: the engine takes the lower cloud
+                                  index, the reference whatever its map tree visits first (not
+                                  reproduced; ~2e-7 per sample) */
   double ms_bfs_loop;          /* device path: wall time of the level loop */
   double ms_deferred;          /* device path: wall time of the deferred edge evaluations */
 } TrgStats;
@@ -203,6 +209,10 @@ TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, 
  * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot).  Both modes give identical
  * graphs; the env var TRG_REPLAY=host sets the default. */
 TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value);
+/* Tiled builds (multi-GPU; an extension, not a reference interface): restrict
+ * node creation to the core region [x0,x1) x [y0,y1) -- a sample outside it counts as a rejected
+ * draw -- and give the tile its own sampler epoch.  core_xyxy == NULL restores the whole plane. */
+TrgStatus trg_engine_set_tile(TrgEngine *e, const float core_xyxy[4], uint32_t epoch);
 /* why the last build fell back from the device path to the host replay ("" if it did not) */
 const char *trg_engine_fallback_reason(const TrgEngine *e);
 

@@ -45,6 +45,7 @@ def lib():
         L.trg_oracle_set_kd_backend.argtypes = [C.c_int, C.c_char_p]
         L.trg_oracle_set_sampler.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int]
         L.trg_oracle_set_cov_f64.argtypes = [C.c_void_p, C.c_int]
+        L.trg_oracle_set_tile.argtypes = [C.c_void_p, fp, C.c_uint32]
         L.trg_oracle_set_trace.argtypes = [C.c_void_p, C.c_int]
         L.trg_oracle_get_table.argtypes = [C.c_void_p, fp, fp]
         L.trg_oracle_set_global_map.argtypes = [C.c_void_p, fp, C.c_size_t, C.c_size_t]
@@ -137,6 +138,11 @@ class Oracle:
     def set_sampler(self, seed=1, mode=0, table_bits=16):
         self.table_bits = table_bits
         self.L.trg_oracle_set_sampler(self.h, mode, seed, table_bits)
+
+    def set_tile(self, core_xyxy, epoch=0):
+        """Tiled-build extension: node creation restricted to [x0,x1) x [y0,y1), sampler epoch."""
+        c = np.ascontiguousarray(core_xyxy, dtype=np.float32)
+        self.L.trg_oracle_set_tile(self.h, _f(c), int(epoch))
 
     def set_cov_f64(self, on):
         self.L.trg_oracle_set_cov_f64(self.h, int(on))

@@ -754,7 +754,7 @@ class Oracle {
         cnt_.trials++;
         float sx = node->pos_[0] + expand_dist * cs;
         float sy = node->pos_[1] + expand_dist * sn;
-        if (isCollision(sx, sy, type, param_.collision_threshold)) {
+        if (isCollision(sx, sy, type, param_.collision_threshold) || !inCore(sx, sy)) {
           trial_sample++;
           continue;
         }
@@ -814,7 +814,7 @@ class Oracle {
   bool initGraph(const float start3d[3]) {
     OGraph &g = global_;
     resetGraph(0);
-    epoch_ = 0;
+    epoch_ = epoch_base_;
     next_cid_ = 0;
     all_created_.clear();
     wire_trace_.clear();
@@ -825,7 +825,7 @@ class Oracle {
     float rx = g.root_pos[0], ry = g.root_pos[1];
     rx = rx + param_.expand_dist;
     int cnt = 0;
-    while (!addNode(g.node_id, rx, ry, ST_VALID, 0)) {
+    while (!inCore(rx, ry) || !addNode(g.node_id, rx, ry, ST_VALID, 0)) {
       if (cnt > 100) {
         return false;
       }
@@ -1137,6 +1137,16 @@ class Oracle {
     return s;
   }
 
+  // Tiled-build extension (not in the reference): nodes may only be
+  // created inside the core region, a sample outside it counts as a rejected (colliding) draw.
+  // The default core is the whole plane, which leaves the reference behaviour untouched.
+  float core_[4] = {-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(),
+                    std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity()};
+  uint32_t epoch_base_ = 0;
+  bool inCore(float x, float y) const {
+    return x >= core_[0] && x < core_[2] && y >= core_[1] && y < core_[3];
+  }
+
   OParams param_;
   KdApi kd_;  // backend captured at construction (own restatement or reference kdtree.c)
   OSampler sampler_;
@@ -1211,6 +1221,11 @@ void trg_oracle_destroy(void *h) { delete (Oracle *)h; }
 
 void trg_oracle_set_sampler(void *h, int mode, uint32_t seed, int table_bits) {
   ((Oracle *)h)->sampler_.configure(mode, seed, table_bits);
+}
+void trg_oracle_set_tile(void *h, const float *core_xyxy, uint32_t epoch) {
+  Oracle *o = (Oracle *)h;
+  for (int i = 0; i < 4; ++i) o->core_[i] = core_xyxy[i];
+  o->epoch_base_ = epoch;
 }
 void trg_oracle_set_cov_f64(void *h, int on) { ((Oracle *)h)->cov_f64_ = on != 0; }
 void trg_oracle_set_trace(void *h, int on) { ((Oracle *)h)->trace_wires_ = on != 0; }

@@ -47,6 +47,14 @@ int main() {
     const int g = grid.nearest(qx, qy, &tie);
     if (tie) {
       ++ties;
+      // the tree-free exact tie-break must name the node the kd-tree returns
+      std::vector<int> tied;
+      grid.tied_set(qx, qy, grid.dist2(g, qx, qy), tied);
+      const int w = trg::kd_tie_winner(xs.data(), ys.data(), (int)xs.size(), qx, qy, tied);
+      if (tied.size() < 2 || w != want) {
+        printf("tie-break mismatch at %d: %d vs %d (tied %zu)\n", i, w, want, tied.size());
+        return 1;
+      }
     } else if (g != want) {
       printf("NodeGrid nearest mismatch at %d: %d vs %d\n", i, g, want);
       return 1;

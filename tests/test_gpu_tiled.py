@@ -1,0 +1,64 @@
+"""GPU: tiled (multi-GPU style) build against the tiled CPU oracle.  The ranks are emulated one
+after the other on the single GPU of the test box -- the per-tile work and the stitch rule are
+exactly what every rank runs; the collective itself is covered by tests/test_dist_gloo.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("layout", [(2, 1), (2, 2)])
+def test_tiled_build_matches_tiled_oracle(oa, synth, layout):
+    import trg_planner
+    from trg_planner import tiled
+    import tiled_oracle
+    cols, rows = layout
+    nx = ny = 130
+    halo = 11  # 1.1 m at 0.1 m spacing
+    prm = dict(oa.MOUNTAIN)
+    terrain = dict(amplitude=2.0, wavelength=20.0)
+    seed, sseed = 77, 9
+    cores = tiled.tile_cores(cols, rows, nx, ny)
+    engines, graphs = [], []
+    for t, core in enumerate(cores):
+        win = tiled.tile_lattice_window(t, cols, rows, nx, ny, halo)
+        cloud = synth.mountain_tile(*win, seed=seed, **terrain)
+        e = trg_planner.Engine(**prm)
+        e.set_sampler(sseed, 16)
+        e.set_tile(core, epoch=t)
+        e.set_global_map(cloud)
+        e.init_graph([0.5 * (core[0] + core[2]), 0.5 * (core[1] + core[3]), 0.0])
+        assert e.stats()["used_device_bfs"] == 1, e.fallback_reason
+        engines.append(e)
+        graphs.append(e.graph("global"))
+    all_idx = [tiled.boundary_nodes(g.xyz, cores[t], cols, rows, t, prm["expand_dist"])
+               for t, g in enumerate(graphs)]
+    all_xyz = [np.ascontiguousarray(g.xyz[i], np.float32) for g, i in zip(graphs, all_idx)]
+    parts = [tiled.stitch_local(t, all_idx, all_xyz, prm["expand_dist"], e.edge_risk)
+             for t, e in enumerate(engines)]
+    stitched = tuple(np.concatenate([p[k] for p in parts], 0) for k in range(3))
+    G = tiled.assemble_global(graphs, stitched)
+
+    o_graphs, o_stitched, OG = tiled_oracle.build_tiled_oracle(
+        oa, synth, tiled, prm, cols, rows, nx, ny, halo, seed, sseed, terrain)
+    # every node inside its core; tiles equal the oracle's tiles
+    for t, (g, og) in enumerate(zip(graphs, o_graphs)):
+        c = cores[t]
+        assert ((g.xyz[:, 0] >= c[0]) & (g.xyz[:, 0] < c[2]) & (g.xyz[:, 1] >= c[1]) &
+                (g.xyz[:, 1] < c[3])).all()
+        assert g.V == og.V and np.array_equal(g.col, og.col) and np.array_equal(g.xyz, og.xyz)
+    assert stitched[0].shape[0] > 10                      # the seam really got edges
+    assert np.array_equal(stitched[0], o_stitched[0])
+    assert G["V"] == OG["V"] and np.array_equal(G["rowptr"], OG["rowptr"])
+    assert np.array_equal(G["col"], OG["col"]) and np.array_equal(G["state"], OG["state"])
+    assert np.array_equal(G["xyz"].view(np.uint32), OG["xyz"].view(np.uint32))
+    assert np.array_equal(G["dist"].view(np.uint32), OG["dist"].view(np.uint32))
+    assert float(np.abs(G["w"] - OG["w"]).max()) <= TOL
+    # the global graph is symmetric and the seam connects the tiles
+    src = np.repeat(np.arange(G["V"]), np.diff(G["rowptr"]))
+    fwd = set(zip(src.tolist(), G["col"].tolist()))
+    assert all((b, a) in fwd for a, b in fwd)
+    offs = G["offsets"]
+    tile_of = np.searchsorted(offs, np.arange(G["V"]), side="right") - 1
+    assert (tile_of[src] != tile_of[G["col"]]).any()

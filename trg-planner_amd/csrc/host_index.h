@@ -12,6 +12,7 @@
 //                (kdtree.c:282, results are pushed at the list head) and nearest-neighbour ties
 //                (kdtree.c:343, first strictly-nearer in traversal order).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -161,6 +162,69 @@ class NodeKd {
   float bmin_[2] = {0, 0}, bmax_[2] = {0, 0};
 };
 
+// ---- exact nearest-neighbour tie-break without the tree ---------------------------------------------
+// kd_nearest keeps the FIRST node it visits among those at the minimal fp32 squared distance
+// (strict `<` updates, kdtree.c:343; the root is the initial best, kdtree.c:393-396), and it visits
+// nearer subtree -> node -> farther subtree (kdtree.c:327-361).  A pruned subtree never holds the
+// first of the tied nodes (pruning needs an equally near node already found), so the winner is the
+// root if it is among the tied, else the tied node that comes first in the unpruned traversal.
+// Which of two nodes A, B comes first is decided at their lowest common ancestor in the insertion
+// tree.  The tree is never built: a subtree's root is the node with the smallest insertion index
+// inside the subtree's region, so the common path is followed by repeatedly taking the minimum
+// index of a shrinking candidate list.  Cost O(sum of list sizes); used only on exact ties.
+//   px, py: positions in insertion order; only indices < K exist at query time.
+inline int kd_first_of_two(const float *px, const float *py, int K, float qx, float qy, int A, int B) {
+  if (A == B) return A;
+  const float q[2] = {qx, qy};
+  auto coord = [&](int n, int ax) { return ax == 0 ? px[n] : py[n]; };
+  std::vector<int> cur_list, next_list;
+  bool implicit = true;  // first pass: the candidate list is [1, K)
+  int cur = 0, axis = 0;
+  for (int depth = 0; depth < K + 2; ++depth) {
+    const float split = coord(cur, axis);
+    const bool near_is_left = (q[axis] - split) <= 0;
+    if (cur == A || cur == B) {
+      const int other = (cur == A) ? B : A;
+      const bool other_left = coord(other, axis) < split;
+      // other lies in cur's subtree: visited before cur iff it is in the nearer subtree
+      return (other_left == near_is_left) ? other : cur;
+    }
+    const bool a_left = coord(A, axis) < split, b_left = coord(B, axis) < split;
+    if (a_left != b_left) return (a_left == near_is_left) ? A : B;
+    // same side: keep the candidates on that side, the subtree root is the smallest index
+    next_list.clear();
+    int best = -1;
+    auto consider = [&](int n) {
+      if (n == cur) return;
+      if ((coord(n, axis) < split) == a_left) {
+        next_list.push_back(n);
+        if (best < 0 || n < best) best = n;
+      }
+    };
+    if (implicit) {
+      for (int n = 1; n < K; ++n) consider(n);
+      implicit = false;
+    } else {
+      for (int n : cur_list) consider(n);
+    }
+    if (best < 0) return A < B ? A : B;  // cannot happen: A and B are on this side
+    cur_list.swap(next_list);
+    cur = best;
+    axis ^= 1;
+  }
+  return A < B ? A : B;
+}
+
+// winner among a set of nodes that all have the minimal squared distance to (qx, qy)
+inline int kd_tie_winner(const float *px, const float *py, int K, float qx, float qy,
+                         const std::vector<int> &tied) {
+  int w = tied[0];
+  for (int n : tied)
+    if (n == 0) return 0;  // the root is the initial best and equal distances never replace it
+  for (size_t i = 1; i < tied.size(); ++i) w = kd_first_of_two(px, py, K, qx, qy, w, tied[i]);
+  return w;
+}
+
 // Uniform grid over the node positions; cells hold singly linked lists of node slots.
 class NodeGrid {
  public:
@@ -180,6 +244,33 @@ class NodeGrid {
   }
   bool ready() const { return !head_.empty(); }
   size_t size() const { return px_.size(); }
+  const float *xs() const { return px_.data(); }
+  const float *ys() const { return py_.data(); }
+
+  // every slot whose fp32 squared distance to (qx, qy) equals d2 (call after nearest() said tie)
+  void tied_set(float qx, float qy, float d2, std::vector<int> &out) const {
+    out.clear();
+    const float rad = std::sqrt(d2) * 1.001f + 1e-6f;
+    const int cx0 = clampi((int)std::floor((qx - rad - x0_) * inv_), 0, W_ - 1);
+    const int cx1 = clampi((int)std::floor((qx + rad - x0_) * inv_), 0, W_ - 1);
+    const int cy0 = clampi((int)std::floor((qy - rad - y0_) * inv_), 0, H_ - 1);
+    const int cy1 = clampi((int)std::floor((qy + rad - y0_) * inv_), 0, H_ - 1);
+    for (int yy = cy0; yy <= cy1; ++yy)
+      for (int xx = cx0; xx <= cx1; ++xx)
+        for (int s = head_[(size_t)yy * W_ + xx]; s >= 0; s = next_[s]) {
+          float dd = 0;
+          dd += (px_[s] - qx) * (px_[s] - qx);
+          dd += (py_[s] - qy) * (py_[s] - qy);
+          if (dd == d2) out.push_back(s);
+        }
+    std::sort(out.begin(), out.end());
+  }
+  float dist2(int s, float qx, float qy) const {
+    float dd = 0;
+    dd += (px_[s] - qx) * (px_[s] - qx);
+    dd += (py_[s] - qy) * (py_[s] - qy);
+    return dd;
+  }
 
   void insert(float x, float y) {  // slot index == insertion order
     const int slot = (int)px_.size();

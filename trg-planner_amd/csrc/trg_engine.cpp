@@ -273,6 +273,8 @@ struct TrgEngine {
   float *d_cos = nullptr, *d_sin = nullptr;
   int table_bits_dev = 0;
   uint32_t epoch = 0;
+  uint32_t epoch_base = 0;  // tiled builds: sampler epoch of this tile
+  float core[4] = {-INFINITY, -INFINITY, INFINITY, INFINITY};  // tiled builds: node creation region
 
   // graph state: slot == id (ids are dense at all times)
   std::vector<float> nx, ny, nz;
@@ -320,6 +322,7 @@ struct TrgEngine {
   bool pool_valid = true;        // e->edges mirrors csr_global
   bool host_grid_valid = true;   // e->grid holds the current node set
   bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
+  int debug_tie_every = 0;       // test hook: treat every n-th BFS level as tie-affected
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
   TrgStats stats{};
@@ -376,6 +379,10 @@ QueryParams qparams(const TrgEngine *e) {
   q.collision_threshold = e->prm.collision_threshold;
   q.expand_dist = e->prm.expand_dist;
   q.sample_num = e->prm.sample_num;
+  q.core_x0 = e->core[0];
+  q.core_y0 = e->core[1];
+  q.core_x1 = e->core[2];
+  q.core_y1 = e->core[3];
   return q;
 }
 
@@ -1247,7 +1254,7 @@ void read_counters(TrgEngine *e) {
     e->stats.bytes_sample_kernel = 12ull * sh;
     e->stats.bytes_edge_kernel = 12ull * eh;
     e->stats.bytes_spec_kernel = 12ull * ph;
-    e->stats.nn_ties += ties;
+    e->stats.map_nn_ties += ties;
   }
 }
 
@@ -1489,7 +1496,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
   reset_graph_global(e);
   e->real_map_stale = stale_before;
   e->pool_valid = true;
-  e->epoch = 0;
+  e->epoch = e->epoch_base;
   e->calls.clear();
   e->pending_calls.clear();
   e->csr_pre.clear();
@@ -1505,6 +1512,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     int32_t flag = 1;
     st = collision_sync(e, e->gmap, e->prm.collision_threshold, xy, 1, &flag, nullptr, nullptr);
     if (st != TRG_OK) return st;
+    if (!(rx >= e->core[0] && rx < e->core[2] && ry >= e->core[1] && ry < e->core[3])) flag = 1;
     if (!flag) {
       int32_t found = 0;
       st = nearest_z_sync(e, e->gmap, xy, 1, &rz, &found);
@@ -1564,11 +1572,27 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
     else return e->fail(TRG_ERR_INVALID_ARG, "replay must be host or device");
     return TRG_OK;
   }
+  if (k == "debug_tie_every") {
+    e->debug_tie_every = atoi(v.c_str());
+    return TRG_OK;
+  }
   if (k == "keep_preclean") {
     e->keep_preclean = v != "0";
     return TRG_OK;
   }
   return e->fail(TRG_ERR_INVALID_ARG, "unknown option " + k);
+}
+
+TrgStatus trg_engine_set_tile(TrgEngine *e, const float core_xyxy[4], uint32_t epoch) {
+  if (!e) return TRG_ERR_INVALID_ARG;
+  if (core_xyxy) {
+    for (int i = 0; i < 4; ++i) e->core[i] = core_xyxy[i];
+  } else {
+    e->core[0] = e->core[1] = -INFINITY;
+    e->core[2] = e->core[3] = INFINITY;
+  }
+  e->epoch_base = epoch;
+  return TRG_OK;
 }
 
 const char *trg_engine_fallback_reason(const TrgEngine *e) {

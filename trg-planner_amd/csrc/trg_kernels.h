@@ -26,6 +26,9 @@ struct QueryParams {
   float collision_threshold;
   float expand_dist;
   int sample_num;
+  // tiled builds: samples outside [core_x0, core_x1) x [core_y0, core_y1) are rejected draws
+  // (default: the whole plane, i.e. the reference behaviour)
+  float core_x0, core_y0, core_x1, core_y1;
 };
 
 // result codes of the position-only part of wireEdge (trg.cpp:269-363)
@@ -169,6 +172,7 @@ void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int co
 constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-resident (<= 512 groups)
 void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
                         int V0, int ncand_bound, hipStream_t s);
+void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
 void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, long long base, int count,
                        DeviceCounters *ctr, hipStream_t s);
 void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);

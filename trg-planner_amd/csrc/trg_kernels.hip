@@ -1340,7 +1340,8 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
     const Disc d =
         disc_query<true>(m, qx, qy, p.robot_size, p.height_threshold, ztile[w], ctr);
     if (lane == 0) {
-      r_col[w] = disc_collides(d, p.collision_threshold) ? 1 : 0;
+      const bool in_core = qx >= p.core_x0 && qx < p.core_x1 && qy >= p.core_y0 && qy < p.core_y1;
+      r_col[w] = (disc_collides(d, p.collision_threshold) || !in_core) ? 1 : 0;
       r_x[w] = qx;
       r_y[w] = qy;
       r_z[w] = d.nn_z;

@@ -65,7 +65,9 @@ class TrgStats(C.Structure):
         ("ms_init_graph_total", C.c_double), ("ms_replay_host", C.c_double),
         ("ms_finalize_host", C.c_double), ("ms_wait_gpu", C.c_double),
         ("bfs_levels", C.c_uint64), ("used_device_bfs", C.c_uint64), ("bfs_fallbacks", C.c_uint64),
-        ("bfs_max_spin", C.c_uint64), ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double)]
+        ("bfs_max_spin", C.c_uint64), ("bfs_host_levels", C.c_uint64),
+        ("map_nn_ties", C.c_uint64),
+        ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
@@ -78,7 +80,7 @@ EXPORTS = [
     "trg_engine_is_collision_batch", "trg_engine_nearest_z_batch", "trg_engine_edge_risk_batch",
     "trg_engine_is_frontier_batch", "trg_engine_get_stats", "trg_engine_get_sampler_table",
     "trg_engine_debug_map_index", "trg_engine_set_option", "trg_engine_fallback_reason",
-    "trg_engine_check_reached", "trg_engine_check_replan",
+    "trg_engine_check_reached", "trg_engine_check_replan", "trg_engine_set_tile",
 ]
 
 
@@ -141,6 +143,7 @@ def load_library():
     L.trg_engine_check_reached.restype = C.c_int32
     L.trg_engine_check_replan.argtypes = [vp, fp, fp, C.c_int32]
     L.trg_engine_check_replan.restype = C.c_int32
+    L.trg_engine_set_tile.argtypes = [vp, fp, C.c_uint32]
     L.trg_engine_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.trg_engine_fallback_reason.argtypes = [vp]
     L.trg_engine_fallback_reason.restype = C.c_char_p
@@ -211,6 +214,14 @@ class Engine:
     def arch(self):
         return self.L.trg_engine_device_arch(self.h).decode()
 
+    def set_tile(self, core_xyxy=None, epoch=0):
+        """Tiled builds: node creation restricted to [x0,x1) x [y0,y1); sampler epoch of the tile."""
+        if core_xyxy is None:
+            self._chk(self.L.trg_engine_set_tile(self.h, None, int(epoch)))
+        else:
+            c = np.ascontiguousarray(core_xyxy, dtype=np.float32)
+            self._chk(self.L.trg_engine_set_tile(self.h, _f(c), int(epoch)))
+
     def set_option(self, key, value):
         self._chk(self.L.trg_engine_set_option(self.h, str(key).encode(), str(value).encode()))
 
@@ -267,6 +278,15 @@ class Engine:
         v = TrgCsrView()
         self._chk(self.L.trg_engine_export_csr(self.h, _KINDS[kind], C.byref(v)))
         return int(v.num_nodes), int(v.num_edges)
+
+    def node_xyz(self, kind="global"):
+        """(V, 3) float32 node positions only (no edge arrays copied)."""
+        v = TrgCsrView()
+        self._chk(self.L.trg_engine_export_csr(self.h, _KINDS[kind], C.byref(v)))
+        if v.num_nodes == 0:
+            return np.zeros((0, 3), np.float32)
+        return np.ctypeslib.as_array(v.node_xyz, shape=(3 * v.num_nodes,)).astype(
+            np.float32, copy=True).reshape(v.num_nodes, 3)
 
     def save_json(self, path):
         self._chk(self.L.trg_engine_save_json(self.h, str(path).encode()))

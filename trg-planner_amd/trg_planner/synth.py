@@ -138,3 +138,52 @@ def voxel_centroids(xyz, leaf):
     uniq, start, counts = np.unique(key_s, return_index=True, return_counts=True)
     sums = np.add.reduceat(xyz[order].astype(np.float64), start, axis=0)
     return (sums / counts[:, None]).astype(np.float32)
+
+
+def _hash_u01(ix, iy, seed, salt):
+    """Counter-based uniform [0,1) per lattice point (splitmix64 finaliser), vectorised."""
+    with np.errstate(over="ignore"):
+        h = (ix.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+             ^ iy.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)
+             ^ np.uint64(seed & 0xFFFFFFFFFFFFFFFF) * np.uint64(0x165667B19E3779F9)
+             ^ np.uint64(salt) * np.uint64(0x27D4EB2F165667C5))
+        h ^= h >> np.uint64(30)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(27)
+        h *= np.uint64(0x94D049BB133111EB)
+        h ^= h >> np.uint64(31)
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def mountain_tile(ix0, ix1, iy0, iy1, seed=20250418, spacing=0.1, jitter=0.02, z_noise=0.01,
+                  amplitude=3.0, wavelength=40.0, shuffle=True):
+    """Points of the GLOBAL lattice indices [ix0, ix1) x [iy0, iy1) of one continuous terrain.
+
+    Jitter and z-noise are functions of the global lattice index, so overlapping windows (a tile's
+    halo and its neighbour's core) contain bit-identical points and the union of all tiles is one
+    consistent cloud.  Used by the tiled multi-GPU build.
+    """
+    out = np.empty(((ix1 - ix0) * (iy1 - iy0), 3), dtype=np.float32)
+    nx = ix1 - ix0
+    rows = max(1, (1 << 21) // max(nx, 1))
+    k = 0
+    for j0 in range(iy0, iy1, rows):
+        j1 = min(iy1, j0 + rows)
+        jj, ii = np.meshgrid(np.arange(j0, j1, dtype=np.int64), np.arange(ix0, ix1, dtype=np.int64),
+                             indexing="ij")
+        ii = ii.ravel()
+        jj = jj.ravel()
+        x = ii * spacing + (2.0 * _hash_u01(ii, jj, seed, 1) - 1.0) * jitter
+        y = jj * spacing + (2.0 * _hash_u01(ii, jj, seed, 2) - 1.0) * jitter
+        z = fbm_height(x, y, seed, amplitude, wavelength) + \
+            (2.0 * _hash_u01(ii, jj, seed, 3) - 1.0) * z_noise
+        m = ii.size
+        out[k:k + m, 0] = x
+        out[k:k + m, 1] = y
+        out[k:k + m, 2] = z
+        k += m
+    if shuffle:
+        rng = np.random.Generator(np.random.PCG64([seed & 0xFFFFFFFF, ix0 & 0xFFFFFFFF,
+                                                   iy0 & 0xFFFFFFFF]))
+        rng.shuffle(out, axis=0)
+    return out

@@ -1,0 +1,175 @@
+"""Tiled multi-GPU TRG build: one terrain tile per rank, boundary edges stitched over RCCL.
+
+This is an EXTENSION of the reference algorithm, not a restatement: the reference grows one graph
+from one root with one FIFO (trg.cpp:372-454), whose order is global and does not shard.  The
+tiled build is defined as follows (the CPU oracle implements the same rule, tests/tiled_oracle.py):
+
+1. Space is cut into a grid of core rectangles.  Rank t holds the map points of core_t plus a halo
+   (>= 1.25*expand_dist + robot_size) and runs the reference BFS on them with
+   one change: a sample outside core_t counts as a rejected draw, so every node of tile t lies in
+   core_t.  Sampler: same seed, epoch = tile index.  cleanGraph runs per tile.
+2. Boundary nodes = nodes closer than expand_dist to a core border shared with another tile.
+   Every rank publishes them (all-gather-v: tile, local id, x, y, z).
+3. For every pair (a in tile t, b in tile u, t < u) with ||a - b|| < expand_dist (fp32 norm as
+   trg.cpp:414) rank t evaluates wireEdge's position-only part for (a, b) on its own map; the
+   successful ones are published (second all-gather-v).
+4. Every node appends its cross edges after its tile-local edges, ordered by the global id of the
+   other endpoint.  Global id = tile offset (exclusive prefix of tile node counts) + local id.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def tile_cores(cols, rows, nx, ny, spacing=0.1):
+    """Core rectangles [x0, y0, x1, y1) of a cols x rows grid of nx x ny lattice tiles (fp32)."""
+    cores = []
+    for r in range(rows):
+        for c in range(cols):
+            cores.append(np.array([c * nx * spacing, r * ny * spacing,
+                                   (c + 1) * nx * spacing, (r + 1) * ny * spacing], np.float32))
+    return cores
+
+
+def tile_lattice_window(tile, cols, rows, nx, ny, halo_pts):
+    """Global lattice index window [ix0, ix1) x [iy0, iy1) of a tile's core + halo, clipped to the
+    whole terrain."""
+    c, r = tile % cols, tile // cols
+    ix0 = max(0, c * nx - halo_pts)
+    ix1 = min(cols * nx, (c + 1) * nx + halo_pts)
+    iy0 = max(0, r * ny - halo_pts)
+    iy1 = min(rows * ny, (r + 1) * ny + halo_pts)
+    return ix0, ix1, iy0, iy1
+
+
+def boundary_nodes(xyz, core, cols, rows, tile, dist):
+    """Indices of the nodes closer than `dist` to a core side that has a neighbouring tile."""
+    c, r = tile % cols, tile // cols
+    x, y = xyz[:, 0], xyz[:, 1]
+    m = np.zeros(xyz.shape[0], bool)
+    d = np.float32(dist)
+    if c > 0:
+        m |= (x - core[0]) < d
+    if c < cols - 1:
+        m |= (core[2] - x) < d
+    if r > 0:
+        m |= (y - core[1]) < d
+    if r < rows - 1:
+        m |= (core[3] - y) < d
+    return np.nonzero(m)[0].astype(np.int32)
+
+
+def allgatherv(arr, dist=None, device=None):
+    """All-gather of per-rank arrays with different leading sizes (RCCL has no native allgatherv:
+    counts first, then padded payloads).  Returns the list of every rank's array."""
+    arr = np.ascontiguousarray(arr)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [arr]
+    import torch
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    width = int(np.prod(arr.shape[1:])) if arr.ndim > 1 else 1
+    pad = max(max(counts), 1)
+    tdtype = torch.from_numpy(np.zeros(1, arr.dtype)).dtype
+    buf = torch.zeros((pad, width), dtype=tdtype, device=dev)
+    if arr.shape[0]:
+        buf[:arr.shape[0]] = torch.from_numpy(arr.reshape(arr.shape[0], width)).to(dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    res = []
+    for o, c in zip(outs, counts):
+        a = o[:c].cpu().numpy()
+        res.append(a.reshape((c,) + arr.shape[1:]))
+    return res
+
+
+def cross_pairs(my_tile, records_per_tile, expand_dist):
+    """Pairs (index into my boundary list, other tile, index into its boundary list) with my tile
+    as the LOWER tile and fp32 planar distance < expand_dist.  records: float32 (k, 3) xyz."""
+    mine = records_per_tile[my_tile]
+    out = []
+    d = np.float32(expand_dist)
+    for u in range(my_tile + 1, len(records_per_tile)):
+        other = records_per_tile[u]
+        if mine.shape[0] == 0 or other.shape[0] == 0:
+            continue
+        # (existing - sample).norm() in fp32: sqrt(dx*dx + dy*dy), no FMA
+        dx = mine[:, None, 0] - other[None, :, 0]
+        dy = mine[:, None, 1] - other[None, :, 1]
+        dist = np.sqrt(dx * dx + dy * dy, dtype=np.float32)
+        ia, ib = np.nonzero(dist < d)
+        for a, b in zip(ia.tolist(), ib.tolist()):
+            out.append((a, u, b))
+    return out
+
+
+def assemble_global(tile_graphs, stitched):
+    """Global CSR from the tile graphs (objects with V, rowptr, col, w, dist, xyz, state) and the
+    stitched cross edges (array rows: tile_a, lid_a, tile_b, lid_b; parallel arrays w, dist)."""
+    sizes = [g.V for g in tile_graphs]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    V = int(offs[-1])
+    ids, w, dist = stitched
+    extra = [[] for _ in range(V)]
+    for k in range(ids.shape[0]):
+        ga = int(offs[ids[k, 0]] + ids[k, 1])
+        gb = int(offs[ids[k, 2]] + ids[k, 3])
+        extra[ga].append((gb, float(w[k]), float(dist[k])))
+        extra[gb].append((ga, float(w[k]), float(dist[k])))
+    rowptr = [0]
+    col, ww, dd = [], [], []
+    xyz = np.concatenate([g.xyz for g in tile_graphs], 0) if V else np.zeros((0, 3), np.float32)
+    state = np.concatenate([g.state for g in tile_graphs], 0) if V else np.zeros(0, np.int32)
+    for t, g in enumerate(tile_graphs):
+        for i in range(g.V):
+            a, b = int(g.rowptr[i]), int(g.rowptr[i + 1])
+            col.extend((g.col[a:b].astype(np.int64) + offs[t]).tolist())
+            ww.extend(g.w[a:b].tolist())
+            dd.extend(g.dist[a:b].tolist())
+            for (gb, w_, d_) in sorted(extra[int(offs[t]) + i]):
+                col.append(gb)
+                ww.append(w_)
+                dd.append(d_)
+            rowptr.append(len(col))
+    return dict(V=V, xyz=xyz, state=state, rowptr=np.array(rowptr, np.int64),
+                col=np.array(col, np.int64), w=np.array(ww, np.float32),
+                dist=np.array(dd, np.float32), offsets=offs)
+
+
+def stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk):
+    """Step 3 for one tile given every tile's boundary records: the cross edges this tile owns
+    (it is the lower tile of the pair).  Returns (ids[k,4] int32, w[k], dist[k])."""
+    pairs = cross_pairs(my_tile, all_xyz, expand_dist)
+    if not pairs:
+        return np.zeros((0, 4), np.int32), np.zeros(0, np.float32), np.zeros(0, np.float32)
+    p1 = np.stack([all_xyz[my_tile][a] for a, _, _ in pairs])
+    p2 = np.stack([all_xyz[u][b] for _, u, b in pairs])
+    st, _, w, d = edge_risk(p1, p2)
+    ok = st == 0
+    ids = np.array([[my_tile, all_idx[my_tile][a], u, all_idx[u][b]] for a, u, b in pairs],
+                   np.int32)[ok]
+    return ids, w[ok].astype(np.float32), d[ok].astype(np.float32)
+
+
+def stitch(my_tile, graph, core, cols, rows, expand_dist, edge_risk, dist=None, device=None):
+    """Steps 2-3 for one rank (rank == tile).  `edge_risk(p1, p2) -> (status, n_pts, w, dist)`
+    evaluates wireEdge's position-only part on this rank's map (the engine's edge_risk_batch).
+    Returns (ids[k,4] int32, w[k], dist[k]) of ALL ranks' stitched edges, identical on every rank,
+    and the number of boundary records exchanged."""
+    bidx = boundary_nodes(graph.xyz, core, cols, rows, my_tile, expand_dist)
+    rec_xyz = np.ascontiguousarray(graph.xyz[bidx], dtype=np.float32)
+    all_idx = allgatherv(bidx, dist, device)
+    all_xyz = allgatherv(rec_xyz, dist, device)
+    if len(all_xyz) == 1:  # single process: nothing to stitch against
+        z = np.zeros(0, np.float32)
+        return (np.zeros((0, 4), np.int32), z, z), 0
+    ids, w, d = stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk)
+    g_ids = allgatherv(ids, dist, device)
+    g_w = allgatherv(w, dist, device)
+    g_d = allgatherv(d, dist, device)
+    return (np.concatenate(g_ids, 0), np.concatenate(g_w, 0), np.concatenate(g_d, 0)), \
+        int(sum(a.shape[0] for a in all_idx))
