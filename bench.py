@@ -83,12 +83,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(1, torch.cuda.device_count())
+    gpu_index = local_rank % ndev
+    coll_dev = torch.device("cuda", gpu_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if world <= ndev:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu_index))
+        else:
+            # rehearsal with more ranks than GPUs (ranks share a card; RCCL refuses that): the
+            # exchange goes over gloo with host tensors, everything else is unchanged
+            dist.init_process_group(backend="gloo")
+            coll_dev = torch.device("cpu")
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    local_rank = gpu_index
 
     import trg_planner
     from trg_planner import synth
@@ -125,7 +135,7 @@ def main():
             g = _G()
             g.xyz = eng.node_xyz("global")
             (ids, _, _), nrec = tiled.stitch(rank, g, core, cols, rows, MOUNTAIN["expand_dist"],
-                                             eng.edge_risk, dist, dev)
+                                             eng.edge_risk, dist, coll_dev)
             mine = int(((ids[:, 0] == rank).sum() + (ids[:, 2] == rank).sum())) if ids.size else 0
             stitch_info["cross_edges"] = int(ids.shape[0])
             stitch_info["boundary_records"] = nrec
@@ -154,7 +164,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        items, dt = tiling.reduce_throughput(items, dt, dist, dev)
+        items, dt = tiling.reduce_throughput(items, dt, dist, coll_dev)
 
     if rank == 0:
         st = eng.stats()

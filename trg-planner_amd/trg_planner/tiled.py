@@ -89,20 +89,31 @@ def allgatherv(arr, dist=None, device=None):
 
 def cross_pairs(my_tile, records_per_tile, expand_dist):
     """Pairs (index into my boundary list, other tile, index into its boundary list) with my tile
-    as the LOWER tile and fp32 planar distance < expand_dist.  records: float32 (k, 3) xyz."""
+    as the LOWER tile and fp32 planar distance < expand_dist.  records: float32 (k, 3) xyz.
+    A kd-tree prefilter (fp64, slightly enlarged radius) finds the candidates, the decision is the
+    reference's fp32 expression (existing - sample).norm() < d, trg.cpp:414."""
+    from scipy.spatial import cKDTree
     mine = records_per_tile[my_tile]
     out = []
     d = np.float32(expand_dist)
+    if mine.shape[0] == 0:
+        return out
     for u in range(my_tile + 1, len(records_per_tile)):
         other = records_per_tile[u]
-        if mine.shape[0] == 0 or other.shape[0] == 0:
+        if other.shape[0] == 0:
             continue
-        # (existing - sample).norm() in fp32: sqrt(dx*dx + dy*dy), no FMA
-        dx = mine[:, None, 0] - other[None, :, 0]
-        dy = mine[:, None, 1] - other[None, :, 1]
-        dist = np.sqrt(dx * dx + dy * dy, dtype=np.float32)
-        ia, ib = np.nonzero(dist < d)
-        for a, b in zip(ia.tolist(), ib.tolist()):
+        tree = cKDTree(other[:, :2].astype(np.float64))
+        hits = tree.query_ball_point(mine[:, :2].astype(np.float64), r=float(expand_dist) * 1.001 + 1e-6)
+        ia = np.repeat(np.arange(mine.shape[0]), [len(h) for h in hits])
+        if ia.size == 0:
+            continue
+        ib = np.concatenate([np.asarray(h, np.int64) for h in hits if len(h)])
+        dx = mine[ia, 0] - other[ib, 0]
+        dy = mine[ia, 1] - other[ib, 1]
+        dist = np.sqrt(dx * dx + dy * dy, dtype=np.float32)  # fp32, no FMA
+        keep = dist < d
+        order = np.lexsort((ib[keep], ia[keep]))
+        for a, b in zip(ia[keep][order].tolist(), ib[keep][order].tolist()):
             out.append((a, u, b))
     return out
 
