@@ -323,6 +323,7 @@ struct TrgEngine {
   bool host_grid_valid = true;   // e->grid holds the current node set
   bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
   int debug_tie_every = 0;       // test hook: treat every n-th BFS level as tie-affected
+  float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
   TrgStats stats{};
@@ -383,6 +384,7 @@ QueryParams qparams(const TrgEngine *e) {
   q.core_y0 = e->core[1];
   q.core_x1 = e->core[2];
   q.core_y1 = e->core[3];
+  q.gate_margin = e->gate_margin;
   return q;
 }
 
@@ -1570,6 +1572,10 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
     if (v == "host") e->use_device_bfs = false;
     else if (v == "device") e->use_device_bfs = true;
     else return e->fail(TRG_ERR_INVALID_ARG, "replay must be host or device");
+    return TRG_OK;
+  }
+  if (k == "debug_gate_margin") {
+    e->gate_margin = (float)atof(v.c_str());
     return TRG_OK;
   }
   if (k == "debug_tie_every") {

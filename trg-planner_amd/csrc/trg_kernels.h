@@ -29,6 +29,9 @@ struct QueryParams {
   // tiled builds: samples outside [core_x0, core_x1) x [core_y0, core_y1) are rejected draws
   // (default: the whole plane, i.e. the reference behaviour)
   float core_x0, core_y0, core_x1, core_y1;
+  // relative half-width of the band in which the device does not call the slope gate itself
+  // (1e-4 by default; tests widen it to exercise the host decision path)
+  float gate_margin;
 };
 
 // result codes of the position-only part of wireEdge (trg.cpp:269-363)

@@ -496,9 +496,10 @@ __device__ __forceinline__ EdgeGeom edge_geometry(const QueryParams &p, float x1
   g.gated = false;
   const double lhs = (double)fabsf(z1 - z2) * (double)p.robot_size;
   const double rhs = (double)p.height_threshold * (double)g.dist;
-  if (lhs > rhs * (1.0 + 1e-4)) {
+  const double margin = (double)p.gate_margin;
+  if (lhs > rhs * (1.0 + margin)) {
     g.gated = true;
-  } else if (!(lhs < rhs * (1.0 - 1e-4))) {
+  } else if (!(lhs < rhs * (1.0 - margin))) {
     g.uncertain = EDGE_GATE_UNCERTAIN;
   }
   // dir = (node2 - node1).normalized(); center = node1 + 0.5 * dist * dir  (trg.cpp:277-278)
