@@ -1294,10 +1294,104 @@ __global__ __launch_bounds__(256) void k_edge_finish(const float *mid, int count
 
 constexpr int SW = 8;  // waves per block in the sampling kernel = trials evaluated per round
 
+// Block-shared neighbour tile of the sampling kernel.  Every draw of a node lies on the circle of
+// radius expand_dist around it, so all its collision discs fall inside one (2*(d+r))^2 box: the
+// block stages the box's points (x, y, z, original index) and the box's cell offsets ONCE, and
+// each wave then reads only the few cell-row segments of its own disc out of LDS.
+constexpr int STILE = 768;   // points in the block tile
+constexpr int SBOX = 10;     // box rows / columns of cells the tile can describe
+constexpr int SHCAP = 256;   // hits per disc kept for the median (denser discs: global fallback)
+
+struct SampleLds {
+  float x[STILE], y[STILE], z[STILE];
+  int perm[STILE];
+  int cs[SBOX][SBOX + 1];  // cs[row][col]: tile offset of the first point of box cell (row, col)
+  float zb[SW][SHCAP];
+  int bx0, by0, ncols, nrows, total;
+};
+
+// isCollision + nearest map point of one disc, candidates read from the block tile
+__device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb, float qx, float qy,
+                                 float r, float h) {
+  const int lane = lane_id();
+  const float r2 = r * r;
+  const CellRange c = cells_for(m, qx, qy, r);
+  // the disc's cells in box coordinates (the box covers them by construction; clamp for safety)
+  const int cx0 = max(c.cx0 - L.bx0, 0), cx1 = min(c.cx1 - L.bx0, L.ncols - 1);
+  const int cy0 = max(c.cy0 - L.by0, 0), cy1 = min(c.cy1 - L.by0, L.nrows - 1);
+  int n = 0;
+  float zmin = FLT_MAX, zmax = -FLT_MAX;
+  float best_d2 = FLT_MAX, best_z = 0.0f;
+  int best_perm = INT_MAX;
+  for (int row = cy0; row <= cy1; ++row) {
+    const int s = L.cs[row][cx0], e = L.cs[row][cx1 + 1];
+    for (int base = s; base < e; base += WAVE) {
+      const int i = base + lane;
+      bool hit = false;
+      float z = 0.0f, d2 = 0.0f;
+      if (i < e) {
+        const float dx = L.x[i] - qx;
+        const float dy = L.y[i] - qy;
+        z = L.z[i];
+        d2 = dx * dx + dy * dy;
+        hit = d2 <= r2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int pos = n + __popcll(mask & lanemask_lt());
+        if (pos < SHCAP) zb[pos] = z;
+        zmin = fminf(zmin, z);
+        zmax = fmaxf(zmax, z);
+        const int pm = L.perm[i];
+        if (d2 < best_d2 || (d2 == best_d2 && pm < best_perm)) {
+          best_d2 = d2;
+          best_z = z;
+          best_perm = pm;
+        }
+      }
+      n += __popcll(mask);
+    }
+  }
+  Disc out;
+  out.n = n;
+  out.cnt = 0;
+  out.nn_z = 0.0f;
+  out.nn_tie = 0;
+  if (n == 0) return out;
+  float wd = best_d2, wz = best_z;
+  int wp = best_perm;
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    const float od = __shfl_xor(wd, msk);
+    const float oz = __shfl_xor(wz, msk);
+    const int op = __shfl_xor(wp, msk);
+    zmin = fminf(zmin, __shfl_xor(zmin, msk));
+    zmax = fmaxf(zmax, __shfl_xor(zmax, msk));
+    if (od < wd || (od == wd && op < wp)) {
+      wd = od;
+      wz = oz;
+      wp = op;
+    }
+  }
+  out.nn_z = wz;
+  out.nn_tie = __ballot(best_perm != INT_MAX && best_d2 == wd && best_perm != wp) != 0ull;
+  // every |z - z_med| <= zmax - zmin (rounding is monotone), so a flat disc needs no median
+  if (!(zmax - zmin <= h)) {
+    if (n <= SHCAP) {
+      wave_lds_sync();
+      out.cnt = median_count(zb, n, h);
+      wave_lds_sync();
+    } else {
+      out.cnt = -1;  // caller falls back to the global-memory query
+    }
+  }
+  return out;
+}
+
 // One block per queued node: the rejection-sampling loop of expandGraph (trg.cpp:384-403).
 // Each round evaluates SW consecutive draws concurrently (one wave per draw); acceptance is
 // then decided in draw order, so the result equals the sequential loop's.
-__global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParams p,
+__global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryParams p,
                                                            const float *cos_t, const float *sin_t,
                                                            int table_bits, uint32_t seed,
                                                            uint32_t epoch, const float *node_xy,
@@ -1306,14 +1400,16 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
                                                            float *sx, float *sy, float *sz,
                                                            DeviceCounters *ctr, const int *front,
                                                            const float *gnx, const float *gny) {
-  __shared__ float ztile[SW][HCAP];
+  __shared__ SampleLds L;
   __shared__ int r_col[SW];
   __shared__ float r_x[SW], r_y[SW], r_z[SW];
   __shared__ unsigned long long r_hits[SW];
   __shared__ int r_ties[SW];
+  __shared__ int s_row[SBOX], row_off[SBOX + 1];
   const int node = blockIdx.x;
   if (node >= count) return;
-  const int w = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6;
   const int lane = lane_id();
   // two addressing modes: chunk arrays (host replay) or frontier ids into the device node arrays
   float px, py;
@@ -1328,6 +1424,57 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
     py = node_xy[2 * node + 1];
     id = (uint32_t)node_id[node];
   }
+
+  // ---- stage the box of all possible discs of this node --------------------------------------
+  const CellRange box = cells_for(m, px, py, p.expand_dist + p.robot_size * 1.002f + 1e-5f);
+  const int ncols = box.cx1 - box.cx0 + 1, nrows = box.cy1 - box.cy0 + 1;
+  bool use_tile = ncols <= SBOX && nrows <= SBOX;
+  if (use_tile) {
+    // absolute cell offsets of the box (one load per thread), then row extents
+    const int ncs = nrows * (ncols + 1);
+    if (tid < ncs) {
+      const int row = tid / (ncols + 1), col = tid - row * (ncols + 1);
+      L.cs[row][col] = m.cell_start[(box.cy0 + row) * m.W + box.cx0 + col];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int row = 0; row < nrows; ++row) {
+        s_row[row] = L.cs[row][0];
+        row_off[row] = acc;
+        acc += L.cs[row][ncols] - L.cs[row][0];
+      }
+      row_off[nrows] = acc;
+      L.total = acc;
+      L.bx0 = box.cx0;
+      L.by0 = box.cy0;
+      L.ncols = ncols;
+      L.nrows = nrows;
+    }
+    __syncthreads();
+    use_tile = L.total <= STILE;
+  }
+  if (use_tile) {
+    const int total = L.total;
+    for (int idx = tid; idx < total; idx += SW * WAVE) {
+      int row = 0;
+      for (int rr = 1; rr < nrows; ++rr) row += (idx >= row_off[rr]);
+      const int src = s_row[row] + (idx - row_off[row]);
+      L.x[idx] = m.x[src];
+      L.y[idx] = m.y[src];
+      L.z[idx] = m.z[src];
+      L.perm[idx] = m.perm[src];
+    }
+    // cell offsets relative to the tile
+    const int ncs = nrows * (ncols + 1);
+    __syncthreads();
+    if (tid < ncs) {
+      const int row = tid / (ncols + 1), col = tid - row * (ncols + 1);
+      L.cs[row][col] = row_off[row] + (L.cs[row][col] - s_row[row]);
+    }
+    __syncthreads();
+  }
+
   const int S = p.sample_num;
   const int max_trial_sample = 1000;
   int n_acc = 0, rejects = 0, draws = 0;
@@ -1338,8 +1485,16 @@ __global__ __launch_bounds__(SW *WAVE) void k_sample_nodes(MapView m, QueryParam
     const uint32_t k = sample_hash(seed, epoch, id, t) >> (32 - table_bits);
     const float qx = px + p.expand_dist * cos_t[k];
     const float qy = py + p.expand_dist * sin_t[k];
-    const Disc d =
-        disc_query<true>(m, qx, qy, p.robot_size, p.height_threshold, ztile[w], ctr);
+    Disc d;
+    bool done_tile = false;
+    if (use_tile) {
+      d = sample_tile_disc(m, L, L.zb[w], qx, qy, p.robot_size, p.height_threshold);
+      done_tile = d.cnt >= 0;
+    }
+    // dense disc or oversized box: the general query (its hit buffer is this wave's LDS slice; a
+    // disc with more hits than that selects the median by re-reading the map)
+    if (!done_tile)
+      d = disc_query<true>(m, qx, qy, p.robot_size, p.height_threshold, L.zb[w], ctr, SHCAP);
     if (lane == 0) {
       const bool in_core = qx >= p.core_x0 && qx < p.core_x1 && qy >= p.core_y0 && qy < p.core_y1;
       r_col[w] = (disc_collides(d, p.collision_threshold) || !in_core) ? 1 : 0;
