@@ -131,12 +131,15 @@ typedef struct TrgStats {
   uint64_t bfs_fallbacks;      /* device path declined and the host replay redid the build */
   uint64_t bfs_max_spin;       /* longest dependency wait (poll iterations) in k_bfs_resolve */
   uint64_t bfs_host_levels;    /* BFS levels replayed on the host because of an exact distance tie */
-  uint64_t map_nn_ties;        /* elevation lookups (trg.cpp:244-247) whose two nearest MAP points are at
-                                  exactly the same fp32 distance: the engine takes the lower cloud
-                                  index, the reference whatever its map tree visits first (not
-                                  reproduced; ~2e-7 per sample) */
+  uint64_t map_nn_ties;        /* nearest-map-point queries (trial discs and elevation lookups,
+                                  trg.cpp:244-247) that met two MAP points at exactly the same fp32
+                                  distance (~2e-7 per query) */
   double ms_bfs_loop;          /* device path: wall time of the level loop */
   double ms_deferred;          /* device path: wall time of the deferred edge evaluations */
+  uint64_t map_nn_resolved;    /* of those, the ones an accepted sample / addNode depended on: decided
+                                  in the reference's map-tree visiting order (kdtree.c:303-362) */
+  uint64_t map_nn_unresolved;  /* ties left at "lowest cloud index" (more than 16 points tied, or more
+                                  than 256 tied samples in one launch) -- 0 in practice */
 } TrgStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

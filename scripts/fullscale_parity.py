@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Full-size parity run (BASELINE config 3: 10 M points, S=16): the engine's graph against the CPU
+oracle's, node by node.  The oracle needs several minutes at this size, so this is a one-off
+evidence run (result written to gpurun_out/ and copied to profiles/), not part of the test suite.
+
+usage: python scripts/fullscale_parity.py [nx ny]   (default 3200 3125)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "trg-planner_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_api as oa  # noqa: E402
+import trg_planner  # noqa: E402
+from trg_planner import synth  # noqa: E402
+
+nx, ny = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3200, 3125)
+out_path = os.path.join(ROOT, "gpurun_out", f"fullscale_parity_{nx}x{ny}.json")
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+prm = dict(oa.MOUNTAIN, sample_num=16)
+t0 = time.time()
+cloud = synth.mountain_tile(0, nx, 0, ny, seed=20250418)
+start = [nx * 0.05, ny * 0.05, 0.0]
+print(f"cloud {cloud.shape} in {time.time() - t0:.1f}s", flush=True)
+
+e = trg_planner.Engine(**prm)
+e.set_sampler(7, 16)
+e.set_option("keep_preclean", 1)
+e.set_global_map(cloud)
+t0 = time.time()
+e.init_graph(start)
+t_engine = time.time() - t0
+st = e.stats()
+ge_pre, ge = e.graph("preclean"), e.graph("global")
+print(f"engine: V'={ge.V} E'={ge.E} in {t_engine:.3f}s  ties node={st['nn_ties']} map={st['map_nn_ties']} "
+      f"host_levels={st['bfs_host_levels']}", flush=True)
+
+oa.use_reference_kd(True)
+o = oa.Oracle(**prm)
+o.set_sampler(7, 0, 16)
+t0 = time.time()
+o.set_global_map(cloud)
+t_index = time.time() - t0
+print(f"oracle index {t_index:.1f}s", flush=True)
+t0 = time.time()
+assert o.init_graph(start)
+t_oracle = time.time() - t0
+go_pre, go = o.graph(1), o.graph(0)
+print(f"oracle: V'={go.V} E'={go.E} in {t_oracle:.1f}s", flush=True)
+
+res = {"nx": nx, "ny": ny, "points": int(cloud.shape[0]), "engine_s": t_engine,
+       "oracle_index_s": t_index, "oracle_init_graph_s": t_oracle,
+       "speedup_init_graph": (t_index + t_oracle) / t_engine,
+       "V_engine": ge.V, "E_engine": ge.E, "V_oracle": go.V, "E_oracle": go.E,
+       "node_ties": st["nn_ties"], "map_nn_ties": st["map_nn_ties"],
+       "bfs_host_levels": st["bfs_host_levels"]}
+
+
+def compare(a, b, tag):
+    r = {"same_V": a.V == b.V, "same_E": a.E == b.E}
+    if a.V == b.V:
+        r["xyz_bitwise_equal_nodes"] = int((a.xyz.view(np.uint32) == b.xyz.view(np.uint32)).all(1).sum())
+        r["state_equal"] = bool(np.array_equal(a.state, b.state))
+        r["rowptr_equal"] = bool(np.array_equal(a.rowptr, b.rowptr))
+    if a.E == b.E and a.V == b.V:
+        r["col_equal"] = bool(np.array_equal(a.col, b.col))
+        r["dist_bitwise_equal_edges"] = int((a.dist.view(np.uint32) == b.dist.view(np.uint32)).sum())
+        dw = np.abs(a.w.astype(np.float64) - b.w.astype(np.float64))
+        r["weight_max_abs_diff"] = float(dw.max()) if dw.size else 0.0
+        r["weight_over_1e-5"] = int((dw > 1e-5).sum())
+    else:
+        n = min(a.V, b.V)
+        diff = np.nonzero((a.xyz[:n].view(np.uint32) != b.xyz[:n].view(np.uint32)).any(1))[0]
+        r["first_differing_node"] = int(diff[0]) if diff.size else None
+    res[tag] = r
+
+
+compare(ge_pre, go_pre, "preclean")
+compare(ge, go, "global")
+json.dump(res, open(out_path, "w"), indent=1)
+print(json.dumps(res, indent=1))

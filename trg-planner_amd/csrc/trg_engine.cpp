@@ -218,6 +218,8 @@ struct Chunk {
   size_t mid_cap = 0;
   View<float> node_xy, node_xyz, sx, sy, sz, weight, dist;
   View<int> node_id, n_acc, n_draws, status;
+  // nearest-map-point ties of accepted samples: [0] = count, records from word 4 (MapTieRec)
+  PinnedBuf<int> mt;
   size_t in_words = 0, out_words = 0;
   void carve(int cnt, int S) {
     const size_t c = (size_t)cnt, cs = c * (size_t)S;
@@ -315,6 +317,9 @@ struct TrgEngine {
   PinnedBuf<int> sy_i0, sy_i1, sy_i2;
   float *sy_mid = nullptr;
   size_t sy_cap = 0;
+  // exact nearest-map-point tie-break scratch (map_nn_exact)
+  MapTieSet *mt_set_d = nullptr, *mt_set_h = nullptr;
+  unsigned long long *mt_key_d = nullptr, *mt_key_h = nullptr;
 
   Csr csr_global, csr_pre, csr_local;
   bool keep_preclean = false;    // instrumentation: snapshot the graph before cleanGraph
@@ -630,6 +635,126 @@ TrgStatus collision_sync(TrgEngine *e, DevMap &m, float threshold, const float *
   return TRG_OK;
 }
 
+// ---- exact nearest-map-point tie-break ------------------------------------------------------------
+// addNode takes the z of kd_nearest's result (trg.cpp:244-247).  When several map points are at the
+// same minimal fp32 distance, kd_nearest returns the one it visits first (strict `<`, kdtree.c:343;
+// the root is the initial best, kdtree.c:393-396), which depends on the shape of the insertion-built
+// map tree.  The tree is never built here: as in kd_first_of_two (host_index.h) the visiting order
+// of two tied points is decided at their lowest common ancestor, and the common path is followed
+// by asking the GPU for "the point with the smallest original index inside this half-open region,
+// inserted after the current ancestor" -- which is exactly the root of that subtree, because
+// kd_insert appends in cloud order and sends `<` to the left (kdtree.c:179-198).
+struct TiePoint {
+  int perm;
+  float x, y;
+};
+
+TrgStatus ensure_tie_scratch(TrgEngine *e) {
+  if (e->mt_set_d) return TRG_OK;
+  HIPCHK(e, hipMalloc((void **)&e->mt_set_d, sizeof(MapTieSet)));
+  HIPCHK(e, hipMalloc((void **)&e->mt_key_d, sizeof(unsigned long long)));
+  HIPCHK(e, hipHostMalloc((void **)&e->mt_set_h, sizeof(MapTieSet), hipHostMallocDefault));
+  HIPCHK(e, hipHostMalloc((void **)&e->mt_key_h, sizeof(unsigned long long), hipHostMallocDefault));
+  return TRG_OK;
+}
+
+// root of the subtree covering [lo, hi) below the ancestor `perm_gt`; *none when the region is empty
+TrgStatus region_root(TrgEngine *e, const DevMap &m, const float lo[2], const float hi[2], int perm_gt,
+                      TiePoint *out, bool *none) {
+  hipStream_t s = e->s_main;
+  HIPCHK(e, hipMemsetAsync(e->mt_key_d, 0xFF, sizeof(unsigned long long), s));
+  launch_region_min_perm(m.view, lo[0], hi[0], lo[1], hi[1], perm_gt, e->mt_key_d, s);
+  HIPCHK(e, hipMemcpyAsync(e->mt_key_h, e->mt_key_d, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  const unsigned long long key = *e->mt_key_h;
+  *none = key == ~0ull;
+  if (*none) return TRG_OK;
+  const size_t sidx = (size_t)(key & 0xFFFFFFFFull);
+  out->perm = (int)(key >> 32);
+  HIPCHK(e, hipMemcpy(&out->x, m.x + sidx, sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(&out->y, m.y + sidx, sizeof(float), hipMemcpyDeviceToHost));
+  return TRG_OK;
+}
+
+// which of the tied points A, B the nearest-neighbour search for q visits first: 0 = A, 1 = B
+TrgStatus map_first_of_two(TrgEngine *e, const DevMap &m, float qx, float qy, const TiePoint &A,
+                           const TiePoint &B, int *first) {
+  const float q[2] = {qx, qy};
+  float lo[2] = {-INFINITY, -INFINITY}, hi[2] = {INFINITY, INFINITY};
+  TiePoint cur{};
+  bool none = false;
+  TrgStatus st = region_root(e, m, lo, hi, -1, &cur, &none);
+  if (st != TRG_OK) return st;
+  int axis = 0;
+  for (int depth = 0; depth < 100000 && !none; ++depth) {
+    const float split = axis ? cur.y : cur.x;
+    const bool near_is_left = (q[axis] - split) <= 0;
+    const float ca = axis ? A.y : A.x, cb = axis ? B.y : B.x;
+    if (cur.perm == A.perm || cur.perm == B.perm) {
+      // the other point lies in cur's subtree: it is visited before cur iff it is on the nearer side
+      const bool cur_is_a = cur.perm == A.perm;
+      const bool other_left = (cur_is_a ? cb : ca) < split;
+      const bool other_first = other_left == near_is_left;
+      *first = cur_is_a ? (other_first ? 1 : 0) : (other_first ? 0 : 1);
+      return TRG_OK;
+    }
+    const bool a_left = ca < split, b_left = cb < split;
+    if (a_left != b_left) {
+      *first = (a_left == near_is_left) ? 0 : 1;
+      return TRG_OK;
+    }
+    if (a_left)
+      hi[axis] = split;
+    else
+      lo[axis] = split;
+    st = region_root(e, m, lo, hi, cur.perm, &cur, &none);
+    if (st != TRG_OK) return st;
+    axis ^= 1;
+  }
+  return e->fail(TRG_ERR_DEVICE, "nearest-point tie-break lost its candidates (internal error)");
+}
+
+// z of the map point kd_nearest returns for (qx, qy), ties decided as the reference's tree does
+TrgStatus map_nn_exact(TrgEngine *e, const DevMap &m, float qx, float qy, float *z, bool *found) {
+  TrgStatus st = ensure_tie_scratch(e);
+  if (st != TRG_OK) return st;
+  hipStream_t s = e->s_main;
+  launch_map_tied_set(m.view, qx, qy, e->prm.robot_size, e->mt_set_d, s);
+  HIPCHK(e, hipMemcpyAsync(e->mt_set_h, e->mt_set_d, sizeof(MapTieSet), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  const MapTieSet T = *e->mt_set_h;
+  *found = T.count > 0;
+  if (!*found) return TRG_OK;
+  const int n = std::min(T.count, MAPTIE_SET_CAP);
+  // lowest original index first, so that an unresolved case equals the hot kernels' provisional pick
+  int order[MAPTIE_SET_CAP];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::sort(order, order + n, [&](int a, int b) { return T.perm[a] < T.perm[b]; });
+  *z = T.z[order[0]];
+  if (T.count == 1) return TRG_OK;
+  if (T.count > MAPTIE_SET_CAP) {
+    e->stats.map_nn_unresolved++;
+    return TRG_OK;
+  }
+  e->stats.map_nn_resolved++;
+  bool same_z = true;
+  for (int i = 1; i < n; ++i) same_z = same_z && T.z[order[i]] == T.z[order[0]];
+  if (same_z) return TRG_OK;
+  if (T.perm[order[0]] == 0) return TRG_OK;  // the root keeps an equal distance (kdtree.c:393-396)
+  int w = order[0];
+  for (int i = 1; i < n; ++i) {
+    const int c = order[i];
+    const TiePoint A{T.perm[w], T.x[w], T.y[w]}, B{T.perm[c], T.x[c], T.y[c]};
+    int first = 0;
+    st = map_first_of_two(e, m, qx, qy, A, B, &first);
+    if (st != TRG_OK) return st;
+    if (first == 1) w = c;
+  }
+  *z = T.z[w];
+  return TRG_OK;
+}
+
 TrgStatus nearest_z_sync(TrgEngine *e, DevMap &m, const float *xy, size_t cnt, float *z,
                          int32_t *found) {
   if (!m.valid) return e->fail(TRG_ERR_NO_MAP, "nearest_z on an empty map");
@@ -650,7 +775,19 @@ TrgStatus nearest_z_sync(TrgEngine *e, DevMap &m, const float *xy, size_t cnt, f
     HIPCHK(e, hipStreamSynchronize(e->s_main));
     HIPCHK(e, hipGetLastError());
     memcpy(z + off, e->sy_f0.h, m_ * sizeof(float));
-    if (found) memcpy(found + off, e->sy_i0.h, m_ * sizeof(int));
+    // found == 2: several map points at the same fp32 distance; ask for the reference's choice
+    std::vector<size_t> tied;
+    for (size_t i = 0; i < m_; ++i) {
+      if (e->sy_i0.h[i] == 2) tied.push_back(i);
+      if (found) found[off + i] = e->sy_i0.h[i] ? 1 : 0;
+    }
+    for (size_t i : tied) {
+      bool f = false;
+      float zz = 0;
+      st = map_nn_exact(e, m, xy[2 * (off + i)], xy[2 * (off + i) + 1], &zz, &f);
+      if (st != TRG_OK) return st;
+      if (f) z[off + i] = zz;
+    }
   }
   e->stats.sync_batches++;
   return TRG_OK;
@@ -836,6 +973,7 @@ TrgStatus ensure_chunks(TrgEngine *e) {
     }
     HIPCHK(e, alloc_pinned(c.in_blob, 6 * cmax));
     HIPCHK(e, alloc_pinned(c.out_blob, 2 * cmax + 6 * slots));
+    HIPCHK(e, alloc_pinned(c.mt, 4 + 4 * (size_t)MAPTIE_CAP));
     if (c.mid_cap < slots) {
       if (c.d_mid) (void)hipFree(c.d_mid);
       c.d_mid = nullptr;
@@ -880,15 +1018,18 @@ TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
   HIPCHK(e, hipMemcpyAsync(c.in_blob.d, c.in_blob.h, c.in_words * sizeof(uint32_t),
                            hipMemcpyHostToDevice, s));
   const QueryParams q = qparams(e);
+  HIPCHK(e, hipMemsetAsync(c.mt.d, 0, sizeof(int), s));
   HIPCHK(e, hipEventRecord(c.t0, s));
   launch_sample_nodes(e->gmap.view, q, e->d_cos, e->d_sin, e->sampler.table_bits, e->sampler.seed,
                       e->epoch, c.node_xy.d, c.node_id.d, count, c.n_acc.d, c.n_draws.d, c.sx.d,
-                      c.sy.d, c.sz.d, e->d_ctr, s);
+                      c.sy.d, c.sz.d, e->d_ctr, c.mt.d, (MapTieRec *)(c.mt.d + 4), s);
   HIPCHK(e, hipEventRecord(c.t1, s));
   launch_spec_edges(e->gmap.view, q, c.node_xyz.d, count, c.n_acc.d, c.sx.d, c.sy.d, c.sz.d,
                     c.d_mid, c.status.d, nullptr, c.weight.d, c.dist.d, e->d_ctr, s);
   HIPCHK(e, hipEventRecord(c.t2, s));
   HIPCHK(e, hipMemcpyAsync(c.out_blob.h, c.out_blob.d, c.out_words * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipMemcpyAsync(c.mt.h, c.mt.d, (4 + 4 * (size_t)MAPTIE_CAP) * sizeof(int),
                            hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipEventRecord(c.done, s));
   c.in_flight = true;
@@ -906,6 +1047,33 @@ TrgStatus wait_chunk(TrgEngine *e, Chunk &c) {
   if (hipEventElapsedTime(&ms, c.t0, c.t1) == hipSuccess) e->stats.ms_sample_kernel += ms;
   if (hipEventElapsedTime(&ms, c.t1, c.t2) == hipSuccess) e->stats.ms_spec_kernel += ms;
   c.in_flight = false;
+  // accepted samples whose elevation hung on a nearest-point tie: take the point the reference's
+  // map tree returns, and re-evaluate the parent edge if that changed the sample's z
+  const int n_mt = c.mt.h[0];
+  if (n_mt > 0) {
+    const int S = e->prm.sample_num;
+    const MapTieRec *recs = (const MapTieRec *)(c.mt.h + 4);
+    if (n_mt > MAPTIE_CAP) e->stats.map_nn_unresolved += (uint64_t)(n_mt - MAPTIE_CAP);
+    for (int k = 0; k < std::min(n_mt, MAPTIE_CAP); ++k) {
+      const MapTieRec &r = recs[k];
+      float z = 0;
+      bool found = false;
+      TrgStatus st = map_nn_exact(e, e->gmap, r.qx, r.qy, &z, &found);
+      if (st != TRG_OK) return st;
+      if (!found || !(z != c.sz.h[r.slot])) continue;
+      c.sz.h[r.slot] = z;
+      const int qi = r.slot / S;
+      const float p1[3] = {c.node_xyz.h[3 * qi], c.node_xyz.h[3 * qi + 1], c.node_xyz.h[3 * qi + 2]};
+      const float p2[3] = {r.qx, r.qy, z};
+      int32_t stt = 0;
+      float w = 0, d = 0;
+      st = edges_sync(e, e->gmap, p1, p2, 1, &stt, nullptr, &w, &d, true);
+      if (st != TRG_OK) return st;
+      c.status.h[r.slot] = stt;
+      c.weight.h[r.slot] = w;
+      c.dist.h[r.slot] = d;
+    }
+  }
   return TRG_OK;
 }
 
@@ -1384,6 +1552,10 @@ void trg_engine_destroy(TrgEngine *e) {
       if (b.d_mid) (void)hipFree(b.d_mid);
     }
     if (e->sy_mid) (void)hipFree(e->sy_mid);
+    if (e->mt_set_d) (void)hipFree(e->mt_set_d);
+    if (e->mt_key_d) (void)hipFree(e->mt_key_d);
+    if (e->mt_set_h) (void)hipHostFree(e->mt_set_h);
+    if (e->mt_key_h) (void)hipHostFree(e->mt_key_h);
     if (e->bfs) {
       e->bfs->release();
       delete e->bfs;

@@ -20,6 +20,23 @@ struct MapView {
   int n;
 };
 
+// An accepted sample whose nearest map point was not unique (kd_nearest's visiting order decides
+// which one the reference takes, trg.cpp:226-233 -> kdtree.c:303-362); the host resolves these.
+constexpr int MAPTIE_CAP = 256;      // records per sampling launch
+constexpr int MAPTIE_SET_CAP = 16;   // points listed per tie
+struct MapTieRec {
+  int slot;        // sample slot of the launch (node * S + j)
+  float qx, qy;    // the sample position
+  float d2;        // the tied fp32 squared distance
+};
+struct MapTieSet {
+  int count;
+  float d2;
+  int sidx[MAPTIE_SET_CAP];   // index in the cell-sorted arrays
+  int perm[MAPTIE_SET_CAP];   // original (insertion) index
+  float x[MAPTIE_SET_CAP], y[MAPTIE_SET_CAP], z[MAPTIE_SET_CAP];
+};
+
 struct QueryParams {
   float robot_size;
   float height_threshold;
@@ -91,7 +108,13 @@ size_t edge_mid_floats(size_t edges);
 void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
                          int table_bits, uint32_t seed, uint32_t epoch, const float *node_xy,
                          const int *node_id, int count, int *n_acc, int *n_draws, float *sx,
-                         float *sy, float *sz, DeviceCounters *ctr, hipStream_t s);
+                         float *sy, float *sz, DeviceCounters *ctr, int *mt_count,
+                         MapTieRec *mt_rec, hipStream_t s);
+// exact nearest-point tie-break helpers (rare path, see map_nn_exact in trg_engine.cpp)
+void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieSet *d_out,
+                         hipStream_t s);
+void launch_region_min_perm(const MapView &m, float lox, float hix, float loy, float hiy,
+                            int perm_gt, unsigned long long *d_key, hipStream_t s);
 // Speculative parent edges node -> sample for every accepted sample of a chunk:
 //   node_xyz[count*3]; slot = node*S + j evaluated iff j < n_acc[node]
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
@@ -106,7 +129,7 @@ constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, no
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
   BFS_CTR_V = 0, BFS_CTR_MNEXT = 1, BFS_CTR_NCAND = 2, BFS_CTR_NUNC = 3, BFS_CTR_ERR = 4,
-  BFS_CTR_NBPOOL = 5, BFS_CTR_COUNT = 8
+  BFS_CTR_NBPOOL = 5, BFS_CTR_NMAPTIE = 6, BFS_CTR_COUNT = 8
 };
 enum : int {
   BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
@@ -140,6 +163,7 @@ struct BfsDev {
   // uncertain slope gates for the host
   int *unc_list;
   float *unc_rec;
+  MapTieRec *mt_rec;  // MAPTIE_CAP records, count in ctrs[BFS_CTR_NMAPTIE]
   // candidate hash of the level
   int *ht_key, *ht_val, *ht_slot;
   float *ht_x, *ht_y;

@@ -88,6 +88,7 @@ struct Disc {
   int cnt;      // of those, |z - z_med| > height_threshold
   float nn_z;   // z of the nearest point (only when NN)
   int nn_tie;   // another point had the same fp32 d2 as the nearest
+  float nn_d2;  // that distance
 };
 
 // Large-disc fallback: k-th smallest z by radix selection over the candidates, re-read from the
@@ -127,6 +128,7 @@ __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float 
   int n = 0;
   float best_d2 = FLT_MAX, best_z = 0.0f;
   int best_perm = INT_MAX;
+  bool lane_tie = false;  // this lane saw two points at its own best distance
   for (int cy = c.cy0; cy <= c.cy1; ++cy) {
     const int s = m.cell_start[cy * m.W + c.cx0];
     const int e = m.cell_start[cy * m.W + c.cx1 + 1];
@@ -147,6 +149,8 @@ __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float 
         if (pos < cap) zbuf[pos] = z;
         if (NN) {
           const int pm = m.perm[i];
+          if (d2 == best_d2) lane_tie = true;
+          if (d2 < best_d2) lane_tie = false;
           if (d2 < best_d2 || (d2 == best_d2 && pm < best_perm)) {
             best_d2 = d2;
             best_z = z;
@@ -162,6 +166,7 @@ __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float 
   out.cnt = 0;
   out.nn_z = 0.0f;
   out.nn_tie = 0;
+  out.nn_d2 = 0.0f;
   if (n == 0) return out;
 
   if (NN) {
@@ -180,8 +185,10 @@ __device__ Disc disc_query(const MapView &m, float qx, float qy, float r, float 
       }
     }
     out.nn_z = wz;
+    out.nn_d2 = wd;
     // a lane whose own best ties the winner with a different point
-    out.nn_tie = __ballot(best_perm != INT_MAX && best_d2 == wd && best_perm != wp) != 0ull;
+    out.nn_tie =
+        __ballot(best_perm != INT_MAX && best_d2 == wd && (best_perm != wp || lane_tie)) != 0ull;
   }
 
   float zmed;
@@ -245,6 +252,7 @@ __device__ bool nearest_point(const MapView &m, float qx, float qy, float r0, fl
     const CellRange c = cells_for(m, qx, qy, R);
     float best_d2 = FLT_MAX, best_z = 0.0f;
     int best_perm = INT_MAX;
+    bool lane_tie = false;
     for (int cy = c.cy0; cy <= c.cy1; ++cy) {
       const int s = m.cell_start[cy * m.W + c.cx0];
       const int e = m.cell_start[cy * m.W + c.cx1 + 1];
@@ -252,6 +260,8 @@ __device__ bool nearest_point(const MapView &m, float qx, float qy, float r0, fl
         const float dx = m.x[i] - qx, dy = m.y[i] - qy;
         const float d2 = dx * dx + dy * dy;
         const int pm = m.perm[i];
+        if (d2 == best_d2) lane_tie = true;
+        if (d2 < best_d2) lane_tie = false;
         if (d2 < best_d2 || (d2 == best_d2 && pm < best_perm)) {
           best_d2 = d2;
           best_z = m.z[i];
@@ -275,7 +285,8 @@ __device__ bool nearest_point(const MapView &m, float qx, float qy, float r0, fl
     const bool whole = c.cx0 == 0 && c.cy0 == 0 && c.cx1 == m.W - 1 && c.cy1 == m.H - 1;
     if (wp != INT_MAX && (wd <= R * R || whole)) {
       z_out = wz;
-      tie_out = __ballot(best_perm != INT_MAX && best_d2 == wd && best_perm != wp) != 0ull;
+      tie_out =
+          __ballot(best_perm != INT_MAX && best_d2 == wd && (best_perm != wp || lane_tie)) != 0ull;
       return true;
     }
     if (whole) return false;
@@ -1193,8 +1204,108 @@ __global__ __launch_bounds__(QW *WAVE) void k_probe_nearest_z(MapView m, QueryPa
   const bool ok = nearest_point(m, xy[2 * q], xy[2 * q + 1], p.robot_size, zz, tie);
   if (lane_id() == 0) {
     z[q] = ok ? zz : 0.0f;
-    if (found) found[q] = ok ? 1 : 0;
+    // found: 0 = empty map, 1 = unique nearest point, 2 = several at the same fp32 distance (the
+    // host then asks for the one the reference's kd-tree would return)
+    if (found) found[q] = ok ? (tie ? 2 : 1) : 0;
     if (tie && ctr) atomicAdd(&ctr[blockIdx.x % COUNTER_SHARDS].nn_ties, 1ull);
+  }
+}
+
+// ---- exact nearest-point tie-break (rare path) ----------------------------------------------------
+// One wave: the set of map points at the minimal fp32 distance from (qx, qy).
+__global__ __launch_bounds__(WAVE) void k_map_tied_set(MapView m, float qx, float qy, float r0,
+                                                       MapTieSet *out) {
+  const int lane = lane_id();
+  float R = r0;
+  for (int iter = 0; iter < 40; ++iter) {
+    const CellRange c = cells_for(m, qx, qy, R);
+    float wd = FLT_MAX;
+    for (int cy = c.cy0; cy <= c.cy1; ++cy) {
+      const int s = m.cell_start[cy * m.W + c.cx0];
+      const int e = m.cell_start[cy * m.W + c.cx1 + 1];
+      for (int i = s + lane; i < e; i += WAVE) {
+        const float dx = m.x[i] - qx, dy = m.y[i] - qy;
+        const float d2 = dx * dx + dy * dy;
+        wd = fminf(wd, d2);
+      }
+    }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) wd = fminf(wd, __shfl_xor(wd, msk));
+    const bool whole = c.cx0 == 0 && c.cy0 == 0 && c.cx1 == m.W - 1 && c.cy1 == m.H - 1;
+    if (wd != FLT_MAX && (wd <= R * R || whole)) {
+      int n = 0;
+      for (int cy = c.cy0; cy <= c.cy1; ++cy) {
+        const int s = m.cell_start[cy * m.W + c.cx0];
+        const int e = m.cell_start[cy * m.W + c.cx1 + 1];
+        for (int base = s; base < e; base += WAVE) {
+          const int i = base + lane;
+          bool hit = false;
+          if (i < e) {
+            const float dx = m.x[i] - qx, dy = m.y[i] - qy;
+            hit = (dx * dx + dy * dy) == wd;
+          }
+          const unsigned long long mask = __ballot(hit);
+          if (hit) {
+            const int pos = n + __popcll(mask & lanemask_lt());
+            if (pos < MAPTIE_SET_CAP) {
+              out->sidx[pos] = i;
+              out->perm[pos] = m.perm[i];
+              out->x[pos] = m.x[i];
+              out->y[pos] = m.y[i];
+              out->z[pos] = m.z[i];
+            }
+          }
+          n += __popcll(mask);
+        }
+      }
+      if (lane == 0) {
+        out->count = n;
+        out->d2 = wd;
+      }
+      return;
+    }
+    if (whole) break;
+    R *= 2.0f;
+  }
+  if (lane == 0) {
+    out->count = 0;
+    out->d2 = 0.0f;
+  }
+}
+
+// The kd-tree node that roots the subtree of the region [lox, hix) x [loy, hiy), below an ancestor
+// inserted as point number perm_gt: the region's point with the smallest original index above
+// perm_gt (kd_insert descends with `<` to the left, kdtree.c:179-198, so a subtree is exactly the
+// later points of its half-open region).  key = (original index << 32 | sorted index), atomicMin.
+__global__ __launch_bounds__(256) void k_region_min_perm(MapView m, float lox, float hix, float loy,
+                                                         float hiy, int perm_gt,
+                                                         unsigned long long *key) {
+  const int cy0 = cell_coord(loy, m.y0, m.inv_g, m.H), cy1 = cell_coord(hiy, m.y0, m.inv_g, m.H);
+  const int cx0 = cell_coord(lox, m.x0, m.inv_g, m.W), cx1 = cell_coord(hix, m.x0, m.inv_g, m.W);
+  __shared__ unsigned long long red[4];
+  unsigned long long best = ~0ull;
+  for (int cy = cy0 + (int)blockIdx.x; cy <= cy1; cy += (int)gridDim.x) {
+    const int s = m.cell_start[cy * m.W + cx0];
+    const int e = m.cell_start[cy * m.W + cx1 + 1];
+    for (int i = s + (int)threadIdx.x; i < e; i += 256) {
+      const float x = m.x[i], y = m.y[i];
+      const int pm = m.perm[i];
+      if (x >= lox && x < hix && y >= loy && y < hiy && pm > perm_gt) {
+        const unsigned long long k = ((unsigned long long)(unsigned)pm << 32) | (unsigned)i;
+        best = k < best ? k : best;
+      }
+    }
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    const unsigned long long o = __shfl_xor(best, msk);
+    best = o < best ? o : best;
+  }
+  if (lane_id() == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) best = red[i] < best ? red[i] : best;
+    if (best != ~0ull) atomicMin(key, best);
   }
 }
 
@@ -1323,6 +1434,7 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
   float zmin = FLT_MAX, zmax = -FLT_MAX;
   float best_d2 = FLT_MAX, best_z = 0.0f;
   int best_perm = INT_MAX;
+  bool lane_tie = false;
   for (int row = cy0; row <= cy1; ++row) {
     const int s = L.cs[row][cx0], e = L.cs[row][cx1 + 1];
     for (int base = s; base < e; base += WAVE) {
@@ -1343,6 +1455,8 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
         zmin = fminf(zmin, z);
         zmax = fmaxf(zmax, z);
         const int pm = L.perm[i];
+        if (d2 == best_d2) lane_tie = true;
+        if (d2 < best_d2) lane_tie = false;
         if (d2 < best_d2 || (d2 == best_d2 && pm < best_perm)) {
           best_d2 = d2;
           best_z = z;
@@ -1357,6 +1471,7 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
   out.cnt = 0;
   out.nn_z = 0.0f;
   out.nn_tie = 0;
+  out.nn_d2 = 0.0f;
   if (n == 0) return out;
   float wd = best_d2, wz = best_z;
   int wp = best_perm;
@@ -1374,7 +1489,9 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
     }
   }
   out.nn_z = wz;
-  out.nn_tie = __ballot(best_perm != INT_MAX && best_d2 == wd && best_perm != wp) != 0ull;
+  out.nn_d2 = wd;
+  out.nn_tie =
+      __ballot(best_perm != INT_MAX && best_d2 == wd && (best_perm != wp || lane_tie)) != 0ull;
   // every |z - z_med| <= zmax - zmin (rounding is monotone), so a flat disc needs no median
   if (!(zmax - zmin <= h)) {
     if (n <= SHCAP) {
@@ -1399,7 +1516,8 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
                                                            int *n_acc_out, int *n_draws_out,
                                                            float *sx, float *sy, float *sz,
                                                            DeviceCounters *ctr, const int *front,
-                                                           const float *gnx, const float *gny) {
+                                                           const float *gnx, const float *gny,
+                                                           int *mt_count, MapTieRec *mt_rec) {
   __shared__ SampleLds L;
   __shared__ int r_col[SW];
   __shared__ float r_x[SW], r_y[SW], r_z[SW];
@@ -1517,7 +1635,21 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
           sy[slot] = r_y[i];
           sz[slot] = r_z[i];
         }
-        if (i == w && d.nn_tie) ties++;
+        if (i == w && d.nn_tie) {
+          // the accepted sample's elevation hangs on a nearest-point tie: tell the host
+          ties++;
+          if (lane == 0 && mt_count) {
+            const int k = atomicAdd(mt_count, 1);
+            if (k < MAPTIE_CAP) {
+              MapTieRec rec;
+              rec.slot = node * S + n_acc;
+              rec.qx = qx;
+              rec.qy = qy;
+              rec.d2 = d.nn_d2;
+              mt_rec[k] = rec;
+            }
+          }
+        }
         n_acc++;
       }
     }
@@ -1613,11 +1745,24 @@ void launch_edges(const MapView &m, QueryParams p, const float *d_p1, const floa
 void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
                          int table_bits, uint32_t seed, uint32_t epoch, const float *node_xy,
                          const int *node_id, int count, int *n_acc, int *n_draws, float *sx,
-                         float *sy, float *sz, DeviceCounters *ctr, hipStream_t s) {
+                         float *sy, float *sz, DeviceCounters *ctr, int *mt_count,
+                         MapTieRec *mt_rec, hipStream_t s) {
   if (count <= 0) return;
   hipLaunchKernelGGL(k_sample_nodes, dim3(count), dim3(SW * WAVE), 0, s, m, p, cos_t, sin_t,
                      table_bits, seed, epoch, node_xy, node_id, count, n_acc, n_draws, sx, sy, sz,
-                     ctr, (const int *)nullptr, (const float *)nullptr, (const float *)nullptr);
+                     ctr, (const int *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                     mt_count, mt_rec);
+}
+void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieSet *d_out,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_map_tied_set, dim3(1), dim3(WAVE), 0, s, m, qx, qy, r0, d_out);
+}
+void launch_region_min_perm(const MapView &m, float lox, float hix, float loy, float hiy,
+                            int perm_gt, unsigned long long *d_key, hipStream_t s) {
+  // one block per cell row of the region, at most 2048 blocks (rows are strided beyond that)
+  int rows = m.H < 2048 ? m.H : 2048;
+  hipLaunchKernelGGL(k_region_min_perm, dim3(rows), dim3(256), 0, s, m, lox, hix, loy, hiy, perm_gt,
+                     d_key);
 }
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
                        const int *n_acc, const float *sx, const float *sy, const float *sz,

@@ -67,7 +67,8 @@ class TrgStats(C.Structure):
         ("bfs_levels", C.c_uint64), ("used_device_bfs", C.c_uint64), ("bfs_fallbacks", C.c_uint64),
         ("bfs_max_spin", C.c_uint64), ("bfs_host_levels", C.c_uint64),
         ("map_nn_ties", C.c_uint64),
-        ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double)]
+        ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double),
+        ("map_nn_resolved", C.c_uint64), ("map_nn_unresolved", C.c_uint64)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
