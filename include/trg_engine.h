@@ -206,6 +206,17 @@ TrgStatus trg_engine_edge_risk_batch(TrgEngine *e, TrgKind map, const float *p1_
 /* reference: TRG::isFrontier trg.cpp:780-803 */
 TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, int32_t *flag);
 
+/* ---- map ingest: voxel-grid filter --------------------------------------------------------------- */
+/* reference: the pcl::VoxelGrid step of TRGPlanner::loadPrebuiltMap, trg_planner.cpp:91-94
+ * (setLeafSize(voxelSize x3), filter): one point per occupied voxel = centroid of its points,
+ * voxels in ascending voxel index (PCL filters/impl/voxel_grid.hpp applyFilter; PCL is not vendored
+ * by the reference -> parity unpinned, the in-voxel fp32 summation order is ascending point index).
+ * xyz: n host points with `stride` floats each; out_xyz: room for 3*n floats; *n_out = points
+ * written.  *passthrough (optional) = 1 when the leaf is too small for 32-bit voxel indices and the
+ * input was handed through unchanged, as PCL does. */
+TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size_t stride, float leaf,
+                                  float *out_xyz, size_t *n_out, int32_t *passthrough);
+
 /* ---- options ----------------------------------------------------------------------------------- */
 /* "replay" = "device" (default: BFS, dedupe and CSR on the GPU when expandGraph's step 3 is off,
  * trg.cpp:429) | "host" (sequential replay on the host, the only mode for step-3 configs);

@@ -264,6 +264,19 @@ class Oracle:
         return U
 
 
+def voxel_grid(xyz, leaf):
+    """CPU restatement of the pcl::VoxelGrid step (trg_planner.cpp:91-94); parity unpinned (PCL)."""
+    L = lib()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    passthrough = C.c_int(0)
+    L.trg_oracle_voxel_grid.restype = C.c_size_t
+    L.trg_oracle_voxel_grid.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_float,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    m = L.trg_oracle_voxel_grid(_f(xyz), xyz.shape[0], C.c_float(leaf), _f(out), C.byref(passthrough))
+    return out[:m].copy(), bool(passthrough.value)
+
+
 def algorithmic_bytes(n_points, counters, V, E):
     """B_alg = B_index + B_query + B_out."""
     b_index = (12 + 12 + 4) * n_points

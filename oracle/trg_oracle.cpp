@@ -46,6 +46,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1263,6 +1264,78 @@ void trg_oracle_is_collision(void *h, int type, float threshold, const float *xy
 void trg_oracle_nearest_z(void *h, int type, const float *xy, size_t m, float *z) {
   Oracle *o = (Oracle *)h;
   for (size_t i = 0; i < m; ++i) z[i] = o->nearestZ(xy[2 * i], xy[2 * i + 1], type);
+}
+// pcl::VoxelGrid as TRGPlanner::loadPrebuiltMap uses it (trg_planner.cpp:91-94).  PCL is a third-party
+// dependency the reference does not vendor or pin (find_package(PCL), cpp/trg_planner/CMakeLists.txt);
+// this restates the published algorithm of pcl/filters/impl/voxel_grid.hpp (applyFilter, PCL 1.10-
+// 1.14, downsample_all_data irrelevant for PointXYZ, min_points_per_voxel = 0): PARITY UNPINNED --
+// the reference holds no fixture for it.  PCL's std::sort leaves the order inside a voxel
+// unspecified; a stable sort (ascending point index) is used here.
+// out: room for 3*n floats; returns the number of voxels, or n with *passthrough = 1 when the index
+// space would overflow int32 (PCL warns and copies the input).
+size_t trg_oracle_voxel_grid(const float *xyz, size_t n, float leaf, float *out, int *passthrough) {
+  *passthrough = 0;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  size_t finite = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = xyz + 3 * i;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = std::min(mn[a], p[a]);
+      mx[a] = std::max(mx[a], p[a]);
+    }
+    finite++;
+  }
+  if (!finite) return 0;
+  const float inv = 1.0f / leaf;
+  const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1;
+  const int64_t dy = (int64_t)((mx[1] - mn[1]) * inv) + 1;
+  const int64_t dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > (int64_t)INT32_MAX) {
+    memcpy(out, xyz, n * 3 * sizeof(float));
+    *passthrough = 1;
+    return n;
+  }
+  int min_b[3], max_b[3];
+  for (int a = 0; a < 3; ++a) {
+    min_b[a] = (int)std::floor(mn[a] * inv);
+    max_b[a] = (int)std::floor(mx[a] * inv);
+  }
+  const int mul1 = max_b[0] - min_b[0] + 1;
+  const int mul2 = mul1 * (max_b[1] - min_b[1] + 1);
+  std::vector<std::pair<unsigned, unsigned>> iv;  // (voxel index, point index)
+  iv.reserve(finite);
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = xyz + 3 * i;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    const int i0 = (int)(std::floor(p[0] * inv) - (float)min_b[0]);
+    const int i1 = (int)(std::floor(p[1] * inv) - (float)min_b[1]);
+    const int i2 = (int)(std::floor(p[2] * inv) - (float)min_b[2]);
+    iv.emplace_back((unsigned)(i0 + i1 * mul1 + i2 * mul2), (unsigned)i);
+  }
+  std::stable_sort(iv.begin(), iv.end(),
+                   [](const std::pair<unsigned, unsigned> &a, const std::pair<unsigned, unsigned> &b) {
+                     return a.first < b.first;
+                   });
+  size_t nv = 0;
+  for (size_t s = 0; s < iv.size();) {
+    size_t e = s;
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    while (e < iv.size() && iv[e].first == iv[s].first) {
+      const float *p = xyz + 3 * (size_t)iv[e].second;
+      cx += p[0];
+      cy += p[1];
+      cz += p[2];
+      ++e;
+    }
+    const float c = (float)(e - s);
+    out[3 * nv] = cx / c;
+    out[3 * nv + 1] = cy / c;
+    out[3 * nv + 2] = cz / c;
+    ++nv;
+    s = e;
+  }
+  return nv;
 }
 void trg_oracle_is_frontier(void *h, const float *xy, size_t m, int *flag) {
   Oracle *o = (Oracle *)h;

@@ -9,5 +9,9 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx9
 mkdir -p "$HERE/_obj"
 "$HIPCC" $FLAGS -c "$HERE/trg_kernels.hip" -o "$HERE/_obj/trg_kernels.o" "$@"
 "$HIPCC" $FLAGS -c "$HERE/trg_engine.cpp" -o "$HERE/_obj/trg_engine.o"
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/_obj/trg_kernels.o" "$HERE/_obj/trg_engine.o" -o "$HERE/libtrg_engine.so"
+# the voxel filter pulls in rocPRIM's radix sort (slow to compile): rebuilt only when it changed
+if [ ! -f "$HERE/_obj/trg_voxel.o" ] || [ "$HERE/trg_voxel.hip" -nt "$HERE/_obj/trg_voxel.o" ] || [ "$HERE/trg_kernels.h" -nt "$HERE/_obj/trg_voxel.o" ]; then
+  "$HIPCC" $FLAGS -c "$HERE/trg_voxel.hip" -o "$HERE/_obj/trg_voxel.o"
+fi
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/_obj/trg_kernels.o" "$HERE/_obj/trg_engine.o" "$HERE/_obj/trg_voxel.o" -o "$HERE/libtrg_engine.so"
 echo "built $HERE/libtrg_engine.so"

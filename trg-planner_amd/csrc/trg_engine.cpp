@@ -2260,6 +2260,34 @@ TrgStatus trg_engine_edge_risk_batch(TrgEngine *e, TrgKind map, const float *p1_
   return edges_sync(e, *pick_map(e, map), p1_xyz, p2_xyz, m, status, n_pts, weight, dist, true);
 }
 
+TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size_t stride, float leaf,
+                                  float *out_xyz, size_t *n_out, int32_t *passthrough) {
+  REQUIRE_DEVICE(e);
+  if (!n_out || (n && (!xyz || !out_xyz))) return e->fail(TRG_ERR_INVALID_ARG, "null arguments");
+  if (stride < 3) return e->fail(TRG_ERR_INVALID_ARG, "stride must be >= 3 floats");
+  if (!(leaf > 0.0f)) return e->fail(TRG_ERR_INVALID_ARG, "leaf size must be positive");
+  *n_out = 0;
+  if (passthrough) *passthrough = 0;
+  if (n == 0) return TRG_OK;
+  float *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(e, hipMalloc((void **)&d_in, n * stride * sizeof(float)));
+  hipError_t he = hipMalloc((void **)&d_out, n * 3 * sizeof(float));
+  if (he == hipSuccess)
+    he = hipMemcpyAsync(d_in, xyz, n * stride * sizeof(float), hipMemcpyHostToDevice, e->s_main);
+  int status = 0;
+  size_t m = 0;
+  if (he == hipSuccess) he = voxel_grid_filter(d_in, n, stride, leaf, d_out, &m, &status, e->s_main);
+  if (he == hipSuccess && m)
+    he = hipMemcpy(out_xyz, d_out, m * 3 * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (he != hipSuccess)
+    return e->fail(TRG_ERR_DEVICE, std::string("voxel filter: ") + hipGetErrorString(he));
+  *n_out = m;
+  if (passthrough) *passthrough = status;
+  return TRG_OK;
+}
+
 TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, int32_t *flag) {
   REQUIRE_DEVICE(e);
   if (m && (!xy || !flag)) return e->fail(TRG_ERR_INVALID_ARG, "null arguments");

@@ -82,6 +82,9 @@ void launch_bounds(const float *d_xyz, size_t n, size_t stride, unsigned *d_boun
 void launch_cell_count(const float *d_xyz, size_t n, size_t stride, float x0, float y0, float inv_g,
                        int W, int H, int *d_cell_of, int *d_rank, int *d_counts, hipStream_t s);
 // exclusive scan of counts[0..m) into out[0..m], out[m] = total; tmp needs ceil(m/1024)+1 ints
+// voxel-grid downsampling (trg_voxel.hip); *status 1 = leaf too small, input copied through
+hipError_t voxel_grid_filter(const float *d_xyz, size_t n, size_t stride, float leaf, float *d_out,
+                             size_t *n_out, int *status, hipStream_t s);
 void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, hipStream_t s);
 void launch_scatter(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
                     const int *d_rank, const int *d_cell_start, float *x, float *y, float *z,

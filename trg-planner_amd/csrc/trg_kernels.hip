@@ -486,7 +486,12 @@ __device__ float risk_weight(const float cov[3][3], int &clamped) {
 // Phase 1 (one wave per edge) produces the "mid" record: status, point count, dist and the 3x3
 // covariance; phase 2 (k_edge_finish, one THREAD per edge) runs the SVD.  Splitting them keeps the
 // serial ~500-flop Jacobi chain off the 64-lane gather waves.
-constexpr int MID_STRIDE = 12;  // dwords per mid record: status n_pts dist c00 c01 c02 c11 c12 c22 pad*3
+// dwords per mid record: status, n_pts, dist, hits, then the nine fp64 moments of the kept ellipse
+// points (s_x s_y s_z s_xx s_xy s_xz s_yy s_yz s_zz; z relative to node 1), 2 dwords of padding.
+// The covariance is formed by the thread-per-edge finish kernels (mid_covariance).
+constexpr int MID_STRIDE = 24;
+constexpr int MID_HITS = 3;
+constexpr int MID_MOMENTS = 4;
 
 struct EdgeGeom {
   float dist, dirx, diry, cx, cy;
@@ -539,16 +544,19 @@ struct EllipseParams {
   bool is_circle;
 };
 
-// one candidate point of the ellipse gather (trg.cpp:309-325); moments in fp64, z shifted
-__device__ __forceinline__ void ellipse_point(const EllipseParams &ep, float px, float py, float pz,
+// one candidate point of the ellipse gather (trg.cpp:309-325); moments in fp64, z shifted.
+// Returns whether the point was kept; mo.kept / mo.in_range are per-lane counts for callers that
+// have no cheaper way (the global-memory fallback).
+__device__ __forceinline__ bool ellipse_point(const EllipseParams &ep, float px, float py, float pz,
                                               Moments &mo) {
   const float ddx = px - ep.cx, ddy = py - ep.cy;
   const float d2 = ddx * ddx + ddy * ddy;
+  bool keep = false;
   if (d2 <= ep.a2) {
     mo.in_range++;
     const float X = ep.r00 * ddx + ep.r01 * ddy;
     const float Y = ep.r10 * ddx + ep.r11 * ddy;
-    bool keep = ep.is_circle;
+    keep = ep.is_circle;
     if (!ep.is_circle) keep = (X * X) * ep.bb + (Y * Y) * ep.a2 < ep.aabb;
     if (keep) {
       mo.kept++;
@@ -564,6 +572,7 @@ __device__ __forceinline__ void ellipse_point(const EllipseParams &ep, float px,
       mo.s_zz += zd * zd;
     }
   }
+  return keep;
 }
 
 // ---- LDS-staged neighbour tile -------------------------------------------------------------------
@@ -571,18 +580,42 @@ __device__ __forceinline__ void ellipse_point(const EllipseParams &ep, float px,
 // small box.  The wave loads the candidate points of that box ONCE -- every row segment is a
 // contiguous range, all loads are issued back to back -- into a per-wave LDS tile, and every
 // query then scans the tile instead of going back to global memory.
-constexpr int TCAP = 320;            // points per tile (x, y, z) and entries of the hit buffer
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int TCAP = 320;            // points per tile and entries of the hit buffer
 constexpr int TITER = TCAP / WAVE;   // 5
 constexpr int MAXROWS = 32;
 
-struct Tile {
-  float *x, *y, *z, *zb;
+// per-wave LDS: (x, y) interleaved so one 8-byte read feeds the packed distance arithmetic
+struct WaveTile {
+  f2 xy[TCAP];
+  float z[TCAP];
+  float zb[TCAP];
+};
+constexpr int MOM_STRIDE = 64;  // doubles per moment row in the reduction scratch
+static_assert(sizeof(WaveTile) >= (9 * MOM_STRIDE + 63) * sizeof(double),
+              "the moment reduction reuses the dead tile");
+
+// Only the points that can matter are kept in the tile: every segment-walk disc lies inside the
+// capsule of half-width robot_size around the segment (|u| <= r, -r <= t <= dist + r in the
+// segment's frame), and the ellipse gather takes points of the disc of radius a around the centre
+// (the reference rotates by +theta, trg.cpp:302-303, so its ellipse is NOT aligned with the segment
+// and only the disc bounds it).  The capsule bounds are widened by a millimetre, far above any fp32
+// rounding of t and u, so the exact membership tests that follow see every point they could accept;
+// tile order stays ascending.
+struct CapsuleFilter {
+  float x1, y1, dirx, diry;  // segment origin and unit direction
+  float t_lo, t_hi, u_max;   // conservative capsule bounds
+  float cx, cy, a2;          // the gather disc of trg.cpp:304, counted here before filtering
 };
 
-// returns the number of staged candidates, or -1 when the box does not fit (caller falls back)
-__device__ int stage_tile(const MapView &m, const CellRange &c, const Tile &t) {
+// returns the number of staged candidates, or -1 when the box does not fit (caller falls back);
+// in_range = points of the box within the gather disc (the kd_nearest_range2 result size)
+__device__ int stage_tile(const MapView &m, const CellRange &c, WaveTile &t, const CapsuleFilter &f,
+                          int &in_range) {
   const int lane = lane_id();
   const int nrows = c.cy1 - c.cy0 + 1;
+  in_range = 0;
   if (nrows > MAXROWS) return -1;
   int s = 0, e = 0;
   if (lane < nrows) {
@@ -618,17 +651,32 @@ __device__ int stage_tile(const MapView &m, const CellRange &c, const Tile &t) {
       }
     }
   }
+  int n = 0;
 #pragma unroll
   for (int i = 0; i < TITER; ++i) {
-    const int tt = lane + i * WAVE;
-    if (tt < total) {
-      t.x[tt] = rx[i];
-      t.y[tt] = ry[i];
-      t.z[tt] = rz[i];
+    if (i * WAVE < total) {  // wave-uniform
+      const bool act = lane + i * WAVE < total;
+      const float ddx = rx[i] - f.cx, ddy = ry[i] - f.cy;
+      const bool inr = act && (ddx * ddx + ddy * ddy <= f.a2);
+      const float px = rx[i] - f.x1, py = ry[i] - f.y1;
+      const float tt = px * f.dirx + py * f.diry;
+      const float uu = py * f.dirx - px * f.diry;
+      const bool keep = act && (inr || (tt >= f.t_lo && tt <= f.t_hi && fabsf(uu) <= f.u_max));
+      const unsigned long long mask = __ballot(keep);
+      in_range += __popcll(__ballot(inr));
+      if (keep) {
+        const int pos = n + __popcll(mask & lanemask_lt());
+        f2 v;
+        v.x = rx[i];
+        v.y = ry[i];
+        t.xy[pos] = v;
+        t.z[pos] = rz[i];
+      }
+      n += __popcll(mask);
     }
   }
   wave_lds_sync();
-  return total;
+  return n;
 }
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -642,7 +690,28 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// k-th smallest of zb[0..n) by rank counting, then #{|z - z_med| > h}  (trg.cpp:763-772)
+// Wave-wide min / max of order-preserving keys with DPP row shifts and row broadcasts (no LDS
+// traffic); the result is wave-uniform.
+template <bool IS_MIN>
+__device__ __forceinline__ unsigned wave_reduce_key(unsigned v) {
+  const unsigned ident = IS_MIN ? 0xFFFFFFFFu : 0u;
+#define KEY_STEP(ctrl, rowmask)                                                                  \
+  {                                                                                              \
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, ctrl, rowmask,  \
+                                                             0xf, false);                        \
+    v = IS_MIN ? (o < v ? o : v) : (o > v ? o : v);                                              \
+  }
+  KEY_STEP(0x111, 0xf)  // row_shr:1
+  KEY_STEP(0x112, 0xf)  // row_shr:2
+  KEY_STEP(0x114, 0xf)  // row_shr:4
+  KEY_STEP(0x118, 0xf)  // row_shr:8  -> lane 15 of every row holds the row's result
+  KEY_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  KEY_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+#undef KEY_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// k-th smallest of zb[0..n) by rank counting, then #{|z - z_med| > h}  (trg.cpp:763-772); any n
 __device__ int median_count(const float *zb, int n, float h) {
   const int lane = lane_id();
   const int k = n / 2;
@@ -667,8 +736,40 @@ __device__ int median_count(const float *zb, int n, float h) {
   return wave_sum(cnt);
 }
 
+// The same statistic for n <= 64 values, one per lane (lane < n holds z): the median's key is
+// found by a most-significant-bit-first radix selection whose bookkeeping runs on the scalar unit
+// (ballot masks and popcounts), two vector instructions per key bit.  key_lo / key_hi are the
+// wave-uniform smallest / largest key of the set: their common leading bits need no selection.
+__device__ __forceinline__ int median_count_lanes(float z, int n, float h, unsigned key_lo,
+                                                  unsigned key_hi) {
+  const int lane = lane_id();
+  const unsigned key = float_key(z);
+  unsigned long long alive = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+  int k = n / 2;  // pts[pts.size() / 2] after the ascending sort (trg.cpp:764)
+  const unsigned diff = key_lo ^ key_hi;
+  unsigned prefix = key_lo;
+  if (diff) {
+    const int top = 31 - __clz((int)diff);
+    prefix = (top == 31) ? 0u : (key_lo & ~((2u << top) - 1u));
+    for (int bit = top; bit >= 0; --bit) {
+      const unsigned long long ones = __ballot((key >> bit) & 1u);
+      const unsigned long long zeros = alive & ~ones;
+      const int c0 = __popcll(zeros);
+      if (k < c0) {
+        alive = zeros;
+      } else {
+        k -= c0;
+        alive &= ones;
+        prefix |= 1u << bit;
+      }
+    }
+  }
+  const float zmed = key_float(prefix);
+  return __popcll(__ballot(lane < n && fabsf(z - zmed) > h));
+}
+
 // isCollision of one disc, candidates read from the tile.  n_out = points in the disc.
-__device__ bool tile_disc_collides(const Tile &t, int T, float qx, float qy, float r, float h,
+__device__ bool tile_disc_collides(WaveTile &t, int T, float qx, float qy, float r, float h,
                                    float threshold, int &n_out) {
   const int lane = lane_id();
   const float r2 = r * r;
@@ -679,8 +780,9 @@ __device__ bool tile_disc_collides(const Tile &t, int T, float qx, float qy, flo
     bool hit = false;
     float z = 0.0f;
     if (i < T) {
-      const float dx = t.x[i] - qx;
-      const float dy = t.y[i] - qy;
+      const f2 p = t.xy[i];
+      const float dx = p.x - qx;
+      const float dy = p.y - qy;
       z = t.z[i];
       const float d2 = dx * dx + dy * dy;
       hit = d2 <= r2;
@@ -708,23 +810,125 @@ __device__ bool tile_disc_collides(const Tile &t, int T, float qx, float qy, flo
   return ratio > threshold;
 }
 
+
 struct EdgeMidOut {
   int status, n_pts;
   float dist;
-  float c[6];
   int hits;  // map points inside this edge's query radii (instrumentation)
 };
 
-// One wave: the position-only part of TRG::wireEdge up to the covariance (trg.cpp:269-338).
+// covariance = centred^T * centred / (n - 1)  (trg.cpp:337-338) from the fp64 moments, rounded once
+__device__ __forceinline__ void mid_covariance(const float *r, float cov[3][3]) {
+  const double *sm = (const double *)(r + MID_MOMENTS);
+  const int kept = __float_as_int(r[1]);
+  const double n = (double)kept;
+  const double mx = sm[0] / n, my = sm[1] / n, mz = sm[2] / n;
+  const double inv = 1.0 / (double)(kept - 1);
+  cov[0][0] = (float)((sm[3] - n * mx * mx) * inv);
+  cov[0][1] = cov[1][0] = (float)((sm[4] - n * mx * my) * inv);
+  cov[0][2] = cov[2][0] = (float)((sm[5] - n * mx * mz) * inv);
+  cov[1][1] = (float)((sm[6] - n * my * my) * inv);
+  cov[1][2] = cov[2][1] = (float)((sm[7] - n * my * mz) * inv);
+  cov[2][2] = (float)((sm[8] - n * mz * mz) * inv);
+}
+
+// Wave-wide sums of the nine moments, written straight into the mid record.  Instead of nine
+// 6-step butterflies (108 cross-lane moves, 54 fp64 adds) the per-lane partials go through the
+// dead tile: 63 lanes each add ten partials of one moment, then one lane per moment adds the seven
+// part sums -- 17 dependent fp64 adds in a fixed order (deterministic, independent of scheduling).
+__device__ __forceinline__ void reduce_store_moments(WaveTile &t, const Moments &mo, float *rec) {
+  const int lane = lane_id();
+  double *P = (double *)&t;
+  wave_lds_sync();  // every lane is done reading the tile
+  P[0 * MOM_STRIDE + lane] = mo.s_x;
+  P[1 * MOM_STRIDE + lane] = mo.s_y;
+  P[2 * MOM_STRIDE + lane] = mo.s_z;
+  P[3 * MOM_STRIDE + lane] = mo.s_xx;
+  P[4 * MOM_STRIDE + lane] = mo.s_xy;
+  P[5 * MOM_STRIDE + lane] = mo.s_xz;
+  P[6 * MOM_STRIDE + lane] = mo.s_yy;
+  P[7 * MOM_STRIDE + lane] = mo.s_yz;
+  P[8 * MOM_STRIDE + lane] = mo.s_zz;
+  wave_lds_sync();
+  const int q = lane / 7, part = lane - q * 7;  // lanes 0..62: moment q, partials [10 part, 10 part + 10)
+  double acc = 0.0;
+  if (lane < 63) {
+    const double *row = P + q * MOM_STRIDE + part * 10;
+    const int cnt = (part == 6) ? 4 : 10;
+    // start each moment's run at a different element so that the nine rows (512 bytes apart, i.e.
+    // the same LDS banks) are not read in lock-step; the order stays fixed per (moment, part)
+    int idx = q % cnt;
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+      if (j < cnt) {
+        acc += row[idx];
+        idx = (idx + 1 == cnt) ? 0 : idx + 1;
+      }
+  }
+  double *Q = P + 9 * MOM_STRIDE;  // 63 part sums, moment-major
+  wave_lds_sync();
+  if (lane < 63) Q[lane] = acc;
+  wave_lds_sync();
+  if (lane < 9) {
+    double tot = 0.0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) tot += Q[lane * 7 + j];
+    ((double *)(rec + MID_MOMENTS))[lane] = tot;
+  }
+}
+
+// Profiling builds (-DTRG_EDGE_STAGE_CUT=n, scripts/edge_microbench.sh) stop the edge evaluation
+// after stage n to attribute its cost; 0 = the product.
+#ifndef TRG_EDGE_STAGE_CUT
+#define TRG_EDGE_STAGE_CUT 0
+#endif
+#define EDGE_CUT(n)                                \
+  if (TRG_EDGE_STAGE_CUT == (n)) {                 \
+    o.status = EDGE_SEG;                           \
+    return o;                                      \
+  }
+
+constexpr int KMAX = 6;  // segment-walk discs of the fast path: dist <= expand_dist + robot_size
+                         // on every edge the build tries
+
+// One pass over the tile for the K discs of the segment walk: per disc the hit count (scalar
+// unit: ballot + popcount) and the smallest / largest z key among its hits.  Branch-free; the
+// (x, y) pairs and the disc centres are packed so the distance is two packed fp32 operations.
+template <int K>
+__device__ __forceinline__ void sweep_discs(const WaveTile &tile, int T, const f2 (&q)[KMAX], float r2,
+                                            int (&cnt)[KMAX], unsigned (&kmn)[KMAX],
+                                            unsigned (&kmx)[KMAX]) {
+  const int lane = lane_id();
+  for (int base = 0; base < T; base += WAVE) {
+    const int i = base + lane;
+    const bool valid = i < T;
+    const int ii = valid ? i : 0;
+    const f2 p = tile.xy[ii];
+    const unsigned zk = float_key(tile.z[ii]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const f2 d = p - q[k];
+      const f2 dd = d * d;
+      const float d2 = dd.x + dd.y;
+      const bool hit = valid && d2 <= r2;
+      cnt[k] += __popcll(__ballot(hit));
+      const unsigned lo = hit ? zk : 0xFFFFFFFFu, hi = hit ? zk : 0u;
+      kmn[k] = lo < kmn[k] ? lo : kmn[k];
+      kmx[k] = hi > kmx[k] ? hi : kmx[k];
+    }
+  }
+}
+
+// One wave: the position-only part of TRG::wireEdge up to the moments of the covariance
+// (trg.cpp:269-338).  Writes the nine moments of an accepted edge into rec; the caller stores the
+// record header from the returned fields.
 __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float x1, float y1,
-                                  float z1, float x2, float y2, float z2, const Tile &tile,
-                                  float *zbuf_big, DeviceCounters *ctr) {
+                                  float z1, float x2, float y2, float z2, WaveTile &tile,
+                                  float *rec, DeviceCounters *ctr) {
   const int lane = lane_id();
   EdgeMidOut o;
   o.n_pts = 0;
   o.hits = 0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) o.c[k] = 0.0f;
   const EdgeGeom g = edge_geometry(p, x1, y1, z1, x2, y2, z2);
   o.dist = g.dist;
   if (g.gated) {
@@ -762,20 +966,37 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
     box.cy0 = cell_coord(ylo, m.y0, m.inv_g, m.H);
     box.cy1 = cell_coord(yhi, m.y0, m.inv_g, m.H);
   }
-  const int T = stage_tile(m, box, tile);
+  CapsuleFilter cf;
+  cf.x1 = x1;
+  cf.y1 = y1;
+  cf.dirx = g.dirx;
+  cf.diry = g.diry;
+  {
+    const float rw = p.robot_size * 1.001f + 1e-3f;
+    cf.t_lo = -rw;
+    cf.t_hi = g.dist + rw;
+    cf.u_max = rw;
+  }
+  cf.cx = ep.cx;
+  cf.cy = ep.cy;
+  cf.a2 = ep.a2;
+  EDGE_CUT(1)  // geometry only
+  int staged_in_range = 0;
+  const int T = stage_tile(m, box, tile, cf, staged_in_range);
+  EDGE_CUT(2)  // + tile staging
 
   unsigned long long hits = 0;
   const float ds = p.robot_size * 0.5f;
 
-  // Fast path: ONE sweep over the staged tile serves every segment-walk disc and the ellipse
-  // gather; the per-disc statistics (count, z-min, z-max) are reduced with interleaved butterflies
-  // and then examined in walk order, so the early exit on the first colliding disc -- and the hit
-  // count the reference would have produced up to it -- are unchanged.
-  constexpr int KMAX = 6;  // dist <= expand_dist + robot_size on every edge the build tries
+  // Fast path: ONE sweep over the staged tile serves every segment-walk disc; the per-disc
+  // statistics are then examined in walk order, so the early exit on the first colliding disc --
+  // and the hit count the reference would have produced up to it -- are unchanged.
   if (T >= 0 && ds > 0.0f) {
-    float qx[KMAX], qy[KMAX];
+    f2 q[KMAX];
     int K = 0;
     bool fits = true;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) q[k] = f2{0.0f, 0.0f};
     for (float i = 0; i < g.dist; i += ds) {  // trg.cpp:283 (float accumulation is semantics)
       if (K == KMAX) {
         fits = false;
@@ -784,47 +1005,35 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if (k == K) {
-          qx[k] = x1 + i * g.dirx;
-          qy[k] = y1 + i * g.diry;
+          q[k].x = x1 + i * g.dirx;
+          q[k].y = y1 + i * g.diry;
         }
       ++K;
     }
     if (fits) {
       const float r2 = p.robot_size * p.robot_size;
       int cnt[KMAX];
-      float zmn[KMAX], zmx[KMAX];
+      unsigned kmn[KMAX], kmx[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         cnt[k] = 0;
-        zmn[k] = FLT_MAX;
-        zmx[k] = -FLT_MAX;
+        kmn[k] = 0xFFFFFFFFu;
+        kmx[k] = 0u;
       }
-      for (int i = lane; i < T; i += WAVE) {
-        const float px = tile.x[i], py = tile.y[i], pz = tile.z[i];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-          if (k < K) {
-            const float dx = px - qx[k];
-            const float dy = py - qy[k];
-            const float d2 = dx * dx + dy * dy;
-            if (d2 <= r2) {
-              cnt[k]++;
-              zmn[k] = fminf(zmn[k], pz);
-              zmx[k] = fmaxf(zmx[k], pz);
-            }
-          }
-        }
+      switch (K) {
+        case 1: sweep_discs<1>(tile, T, q, r2, cnt, kmn, kmx); break;
+        case 2: sweep_discs<2>(tile, T, q, r2, cnt, kmn, kmx); break;
+        case 3: sweep_discs<3>(tile, T, q, r2, cnt, kmn, kmx); break;
+        case 4: sweep_discs<4>(tile, T, q, r2, cnt, kmn, kmx); break;
+        case 5: sweep_discs<5>(tile, T, q, r2, cnt, kmn, kmx); break;
+        case 6: sweep_discs<6>(tile, T, q, r2, cnt, kmn, kmx); break;
+        default: break;  // K == 0: zero-length edge, no disc (trg.cpp:283 never enters the loop)
       }
-#pragma unroll
-      for (int msk = 32; msk >= 1; msk >>= 1) {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-          if (k < K) {
-            cnt[k] += __shfl_xor(cnt[k], msk);
-            zmn[k] = fminf(zmn[k], __shfl_xor(zmn[k], msk));
-            zmx[k] = fmaxf(zmx[k], __shfl_xor(zmx[k], msk));
-          }
-        }
+      if (TRG_EDGE_STAGE_CUT == 3) {  // + disc sweep (keep its results alive)
+        o.status = EDGE_SEG + (cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4] + cnt[5] > 1000000) +
+                   ((kmn[0] ^ kmn[1] ^ kmn[2] ^ kmn[3] ^ kmn[4] ^ kmn[5] ^ kmx[0] ^ kmx[1] ^ kmx[2] ^
+                     kmx[3] ^ kmx[4] ^ kmx[5]) == 12345u);
+        return o;
       }
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
@@ -835,26 +1044,34 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
           if (n == 0) {
             col = true;  // trg.cpp:749-752
           } else {
+            const unsigned klo = wave_reduce_key<true>(kmn[k]);
+            const unsigned khi = wave_reduce_key<false>(kmx[k]);
             int bad = 0;
             // every |z - z_med| <= zmax - zmin (rounding is monotone): a flat disc needs no median
-            if (!(zmx[k] - zmn[k] <= p.height_threshold)) {
+            if (!(key_float(khi) - key_float(klo) <= p.height_threshold)) {
+              // compact the disc's z values (ascending tile order) into the hit buffer
               int nn = 0;
               for (int base = 0; base < T; base += WAVE) {
                 const int i = base + lane;
                 bool hit = false;
                 float z = 0.0f;
                 if (i < T) {
-                  const float dx = tile.x[i] - qx[k];
-                  const float dy = tile.y[i] - qy[k];
+                  const f2 d = tile.xy[i] - q[k];
+                  const f2 dd = d * d;
                   z = tile.z[i];
-                  hit = dx * dx + dy * dy <= r2;
+                  hit = dd.x + dd.y <= r2;
                 }
                 const unsigned long long mask = __ballot(hit);
                 if (hit) tile.zb[nn + __popcll(mask & lanemask_lt())] = z;
                 nn += __popcll(mask);
               }
               wave_lds_sync();
-              bad = median_count(tile.zb, n, p.height_threshold);
+              if (n <= WAVE) {
+                const float zl = tile.zb[lane < n ? lane : 0];
+                bad = median_count_lanes(zl, n, p.height_threshold, klo, khi);
+              } else {
+                bad = median_count(tile.zb, n, p.height_threshold);
+              }
               wave_lds_sync();
             }
             col = (float)bad / (float)n > p.collision_threshold;
@@ -866,19 +1083,25 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
           }
         }
       }
-      // second sweep: ellipse gather (kept apart from the disc sweep to bound register pressure),
-      // then interleaved butterflies for its moments
+      EDGE_CUT(4)  // + disc reductions, medians, decisions
+      // second sweep: ellipse gather (kept apart from the disc sweep to bound register pressure)
       Moments mo;
-      for (int i = lane; i < T; i += WAVE) ellipse_point(ep, tile.x[i], tile.y[i], tile.z[i], mo);
-      int in_range = mo.in_range, kept = mo.kept;
-      double sm[9] = {mo.s_x, mo.s_y, mo.s_z, mo.s_xx, mo.s_xy, mo.s_xz, mo.s_yy, mo.s_yz, mo.s_zz};
-#pragma unroll
-      for (int msk = 32; msk >= 1; msk >>= 1) {
-        in_range += __shfl_xor(in_range, msk);
-        kept += __shfl_xor(kept, msk);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) sm[q] += __shfl_xor(sm[q], msk);
+      int kept = 0;
+      for (int base = 0; base < T; base += WAVE) {
+        const int i = base + lane;
+        bool keep = false;
+        if (i < T) {
+          const f2 pt = tile.xy[i];
+          keep = ellipse_point(ep, pt.x, pt.y, tile.z[i], mo);
+        }
+        kept += __popcll(__ballot(keep));
       }
+      if (TRG_EDGE_STAGE_CUT == 5) {  // + ellipse sweep
+        o.status = EDGE_SEG + (mo.s_x + mo.s_y + mo.s_z + mo.s_xx + mo.s_xy + mo.s_xz + mo.s_yy +
+                                   mo.s_yz + mo.s_zz == 12345.0) + (kept > 100000);
+        return o;
+      }
+      const int in_range = staged_in_range;  // counted over the whole box, before the capsule cut
       hits += (unsigned long long)in_range;
       o.hits = (int)hits;
       o.n_pts = kept;
@@ -890,15 +1113,7 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
         o.status = EDGE_FEW | g.uncertain;
         return o;
       }
-      const double n = (double)kept;
-      const double mx = sm[0] / n, my = sm[1] / n, mz = sm[2] / n;
-      const double inv = 1.0 / (double)(kept - 1);
-      o.c[0] = (float)((sm[3] - n * mx * mx) * inv);
-      o.c[1] = (float)((sm[4] - n * mx * my) * inv);
-      o.c[2] = (float)((sm[5] - n * mx * mz) * inv);
-      o.c[3] = (float)((sm[6] - n * my * my) * inv);
-      o.c[4] = (float)((sm[7] - n * my * mz) * inv);
-      o.c[5] = (float)((sm[8] - n * mz * mz) * inv);
+      reduce_store_moments(tile, mo, rec);
       o.status = EDGE_OK | g.uncertain;
       return o;
     }
@@ -917,7 +1132,7 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
                                p.collision_threshold, n);
     } else {
       const Disc d =
-          disc_query<false>(m, qx, qy, p.robot_size, p.height_threshold, zbuf_big, ctr, TCAP);
+          disc_query<false>(m, qx, qy, p.robot_size, p.height_threshold, tile.zb, ctr, TCAP);
       n = d.n;
       col = disc_collides(d, p.collision_threshold);
     }
@@ -933,7 +1148,10 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
   // gather + rotate + filter (trg.cpp:304-325)
   Moments mo;
   if (T >= 0) {
-    for (int i = lane; i < T; i += WAVE) ellipse_point(ep, tile.x[i], tile.y[i], tile.z[i], mo);
+    for (int i = lane; i < T; i += WAVE) {
+      const f2 pt = tile.xy[i];
+      ellipse_point(ep, pt.x, pt.y, tile.z[i], mo);
+    }
   } else {
     const CellRange cr = cells_for(m, g.cx, g.cy, a);
     for (int cyi = cr.cy0; cyi <= cr.cy1; ++cyi) {
@@ -942,7 +1160,7 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
       for (int i = s + lane; i < e; i += WAVE) ellipse_point(ep, m.x[i], m.y[i], m.z[i], mo);
     }
   }
-  const int in_range = wave_sum(mo.in_range);
+  const int in_range = (T >= 0) ? staged_in_range : wave_sum(mo.in_range);
   const int kept = wave_sum(mo.kept);
   hits += (unsigned long long)in_range;
   o.hits = (int)hits;
@@ -955,39 +1173,20 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
     o.status = EDGE_FEW | g.uncertain;
     return o;
   }
-  const double s_x = wave_sum(mo.s_x), s_y = wave_sum(mo.s_y), s_z = wave_sum(mo.s_z);
-  const double s_xx = wave_sum(mo.s_xx), s_xy = wave_sum(mo.s_xy), s_xz = wave_sum(mo.s_xz);
-  const double s_yy = wave_sum(mo.s_yy), s_yz = wave_sum(mo.s_yz), s_zz = wave_sum(mo.s_zz);
-  // covariance = centred^T * centred / (n - 1)  (trg.cpp:337-338), fp64 then rounded once
-  const double n = (double)kept;
-  const double mx = s_x / n, my = s_y / n, mz = s_z / n;
-  const double inv = 1.0 / (double)(kept - 1);
-  o.c[0] = (float)((s_xx - n * mx * mx) * inv);
-  o.c[1] = (float)((s_xy - n * mx * my) * inv);
-  o.c[2] = (float)((s_xz - n * mx * mz) * inv);
-  o.c[3] = (float)((s_yy - n * my * my) * inv);
-  o.c[4] = (float)((s_yz - n * my * mz) * inv);
-  o.c[5] = (float)((s_zz - n * mz * mz) * inv);
+  reduce_store_moments(tile, mo, rec);
   o.status = EDGE_OK | g.uncertain;
   return o;
 }
 
-// lanes 0..8 of the wave store one mid record as a single contiguous 36-byte write
-__device__ __forceinline__ void store_mid(float *mid, int q, const EdgeMidOut &o) {
-  const int lane = lane_id();
-  if (lane < 10) {
-    float v;
-    switch (lane) {
-      case 0: v = __int_as_float(o.status); break;
-      case 1: v = __int_as_float(o.n_pts); break;
-      case 2: v = o.dist; break;
-      default: v = o.c[0]; break;
-    }
-#pragma unroll
-    for (int k = 1; k < 6; ++k)
-      if (lane == 3 + k) v = o.c[k];
-    if (lane == 9) v = __int_as_float(o.hits);
-    mid[(size_t)q * MID_STRIDE + lane] = v;
+// lane 0 writes the 16-byte header of a mid record (edge_gather wrote the moments)
+__device__ __forceinline__ void store_mid(float *rec, const EdgeMidOut &o) {
+  if (lane_id() == 0) {
+    float4 h;
+    h.x = __int_as_float(o.status);
+    h.y = __int_as_float(o.n_pts);
+    h.z = o.dist;
+    h.w = __int_as_float(o.hits);
+    *(float4 *)rec = h;
   }
 }
 
@@ -1314,7 +1513,7 @@ __global__ __launch_bounds__(256) void k_region_min_perm(MapView m, float lox, f
 static_assert(TCAP % WAVE == 0, "tile capacity is a whole number of wave sweeps");
 constexpr int EDGE_WAVES_PER_SIMD = 6;  // register budget of the edge kernels (<= 80 VGPRs); 5 and 8 measured slower
 struct EdgeLds {
-  float x[QW][TCAP], y[QW][TCAP], z[QW][TCAP], zb[QW][TCAP];
+  WaveTile w[QW];
 };
 
 __global__ __launch_bounds__(QW *WAVE, EDGE_WAVES_PER_SIMD) void k_edges(MapView m, QueryParams p, const float *p1,
@@ -1324,14 +1523,10 @@ __global__ __launch_bounds__(QW *WAVE, EDGE_WAVES_PER_SIMD) void k_edges(MapView
   const int w = threadIdx.x >> 6;
   const int q = blockIdx.x * QW + w;
   if (q >= count) return;
-  Tile t;
-  t.x = lds.x[w];
-  t.y = lds.y[w];
-  t.z = lds.z[w];
-  t.zb = lds.zb[w];
+  float *rec = mid + (size_t)q * MID_STRIDE;
   const EdgeMidOut o = edge_gather(m, p, p1[3 * q], p1[3 * q + 1], p1[3 * q + 2], p2[3 * q],
-                                   p2[3 * q + 1], p2[3 * q + 2], t, lds.zb[w], ctr);
-  store_mid(mid, q, o);
+                                   p2[3 * q + 1], p2[3 * q + 2], lds.w[w], rec, ctr);
+  store_mid(rec, o);
 }
 
 __global__ __launch_bounds__(QW *WAVE, EDGE_WAVES_PER_SIMD) void k_spec_edges(MapView m, QueryParams p,
@@ -1347,15 +1542,11 @@ __global__ __launch_bounds__(QW *WAVE, EDGE_WAVES_PER_SIMD) void k_spec_edges(Ma
   const int node = slot / S;
   const int j = slot - node * S;
   if (j >= n_acc[node]) return;
-  Tile t;
-  t.x = lds.x[w];
-  t.y = lds.y[w];
-  t.z = lds.z[w];
-  t.zb = lds.zb[w];
+  float *rec = mid + (size_t)slot * MID_STRIDE;
   const EdgeMidOut o = edge_gather(m, p, node_xyz[3 * node], node_xyz[3 * node + 1],
-                                   node_xyz[3 * node + 2], sx[slot], sy[slot], sz[slot], t,
-                                   lds.zb[w], ctr);
-  store_mid(mid, slot, o);
+                                   node_xyz[3 * node + 2], sx[slot], sy[slot], sz[slot], lds.w[w],
+                                   rec, ctr);
+  store_mid(rec, o);
 }
 
 // Phase 2: one thread per edge: covariance -> SVD -> risk weight (trg.cpp:339-363).
@@ -1373,7 +1564,7 @@ __global__ __launch_bounds__(256) void k_edge_finish(const float *mid, int count
   }
   const float *r = mid + (size_t)(live ? q : 0) * MID_STRIDE;
   // one atomic per block for the instrumentation counter
-  const int h = wave_sum(live ? __float_as_int(r[9]) : 0);
+  const int h = wave_sum(live ? __float_as_int(r[MID_HITS]) : 0);
   if (lane_id() == 0) wave_hits[threadIdx.x >> 6] = h;
   __syncthreads();
   if (threadIdx.x == 0 && ctr) {
@@ -1387,12 +1578,7 @@ __global__ __launch_bounds__(256) void k_edge_finish(const float *mid, int count
   float w = 0.0f;
   if ((st & EDGE_STATUS_MASK) == EDGE_OK) {
     float cov[3][3];
-    cov[0][0] = r[3];
-    cov[0][1] = cov[1][0] = r[4];
-    cov[0][2] = cov[2][0] = r[5];
-    cov[1][1] = r[6];
-    cov[1][2] = cov[2][1] = r[7];
-    cov[2][2] = r[8];
+    mid_covariance(r, cov);
     int clamped = 0;
     w = risk_weight(cov, clamped);
     st |= clamped;

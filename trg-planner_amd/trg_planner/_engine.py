@@ -82,6 +82,7 @@ EXPORTS = [
     "trg_engine_is_frontier_batch", "trg_engine_get_stats", "trg_engine_get_sampler_table",
     "trg_engine_debug_map_index", "trg_engine_set_option", "trg_engine_fallback_reason",
     "trg_engine_check_reached", "trg_engine_check_replan", "trg_engine_set_tile",
+    "trg_engine_voxel_filter",
 ]
 
 
@@ -89,7 +90,8 @@ def build_library(force=False):
     """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in ("trg_kernels.hip", "trg_kernels.h", "trg_engine.cpp",
                                              "host_index.h", "trg_bfs.inc", "trg_bfs_launch.inc",
-                                             "trg_engine_bfs.inc")]
+                                             "trg_engine_bfs.inc", "trg_voxel.hip",
+                                             "map_order_sim.h")]
     srcs.append(os.path.normpath(os.path.join(CSRC, "..", "..", "include", "trg_engine.h")))
     stale = force or not os.path.exists(LIB_PATH)
     if not stale:
@@ -133,6 +135,8 @@ def load_library():
     L.trg_engine_plan.argtypes = [vp, fp, fp, fp, C.c_int32, C.POINTER(TrgPathInfo)]
     L.trg_engine_refine_path.argtypes = [fp, C.c_int32, fp, C.c_int32]
     L.trg_engine_refine_path.restype = C.c_int32
+    L.trg_engine_voxel_filter.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.c_float, fp,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     L.trg_engine_is_collision_batch.argtypes = [vp, C.c_int, C.c_float, fp, C.c_size_t, ip, ip, ip]
     L.trg_engine_nearest_z_batch.argtypes = [vp, C.c_int, fp, C.c_size_t, fp]
     L.trg_engine_edge_risk_batch.argtypes = [vp, C.c_int, fp, fp, C.c_size_t, ip, ip, fp, fp]
@@ -350,6 +354,16 @@ class Engine:
         self._chk(self.L.trg_engine_edge_risk_batch(self.h, _KINDS[kind], _f(p1), _f(p2), m,
                                                     _i(status), _i(n_pts), _f(w), _f(d)))
         return status, n_pts, w, d
+
+    def voxel_filter(self, xyz, leaf):
+        """pcl::VoxelGrid of TRGPlanner::loadPrebuiltMap (trg_planner.cpp:91-94) on the GPU."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        out = np.empty_like(xyz)
+        n_out = C.c_size_t(0)
+        passthrough = C.c_int32(0)
+        self._chk(self.L.trg_engine_voxel_filter(self.h, _f(xyz), xyz.shape[0], 3, C.c_float(leaf),
+                                                 _f(out), C.byref(n_out), C.byref(passthrough)))
+        return out[:n_out.value].copy()
 
     def is_frontier(self, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)

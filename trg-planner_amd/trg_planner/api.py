@@ -61,6 +61,10 @@ class TRG:
     def setGlobalMap(self, cloud_xyz):
         self.engine.set_global_map(cloud_xyz)
 
+    def voxelFilter(self, cloud_xyz, leaf):
+        """The pcl::VoxelGrid step of TRGPlanner::loadPrebuiltMap (trg_planner.cpp:91-94)."""
+        return self.engine.voxel_filter(cloud_xyz, leaf)
+
     def setLocalMap(self, start2d, cloud_xyz):
         self.engine.set_local_map(start2d, cloud_xyz)
 

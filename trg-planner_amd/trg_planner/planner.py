@@ -88,7 +88,7 @@ class TRGPlanner:
             raise ValueError("Unsupported map type")
         path = p.preMapPath if os.path.isabs(p.preMapPath) else os.path.join(self._map_root, p.preMapPath)
         raw = _pcd.read_pcd(path)
-        self.cs_["preMapPtr"] = _synth.voxel_centroids(raw, p.VoxelSize) if p.isVoxelize else raw
+        self.cs_["preMapPtr"] = self.trg_.voxelFilter(raw, p.VoxelSize) if p.isVoxelize else raw
 
     # ---- FSMs, PL.cpp:131-312 ---------------------------------------------------------------
     def _graph_step(self):
