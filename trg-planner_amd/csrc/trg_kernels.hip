@@ -35,6 +35,11 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }
 
+// ballot of a bool without the int round trip of __ballot()
+__device__ __forceinline__ unsigned long long ballot(bool pred) {
+  return __builtin_amdgcn_ballot_w64(pred);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS traffic of one wave is in order; this only stops the compiler from moving accesses
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -624,15 +629,20 @@ __device__ int stage_tile(const MapView &m, const CellRange &c, WaveTile &t, con
     e = m.cell_start[base + c.cx1 + 1];
   }
   const int len = e - s;
-  int inc = len;  // inclusive prefix of row lengths over lanes
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    const int up = __shfl_up(inc, d);
-    if (lane >= d) inc += up;
-  }
-  const int total = __shfl(inc, WAVE - 1);
+  // inclusive prefix of the row lengths over the lanes (rows only occupy the first 32 lanes):
+  // DPP row shifts inside each 16-lane row, then lane 15's total into the second row
+  int inc = len;
+#define SCAN_STEP(ctrl, rowmask) \
+  inc += __builtin_amdgcn_update_dpp(0, inc, ctrl, rowmask, 0xf, false);
+  SCAN_STEP(0x111, 0xf)  // row_shr:1
+  SCAN_STEP(0x112, 0xf)  // row_shr:2
+  SCAN_STEP(0x114, 0xf)  // row_shr:4
+  SCAN_STEP(0x118, 0xf)  // row_shr:8
+  SCAN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+#undef SCAN_STEP
+  const int total = __builtin_amdgcn_readlane(inc, 31);  // lanes >= nrows hold zero lengths
   if (total > TCAP) return -1;
-  const int excl = inc - len;
+  const int delta = s - (inc - len);  // tile position t of row r lives at map index t + delta[r]
   float rx[TITER], ry[TITER], rz[TITER];
 #pragma unroll
   for (int i = 0; i < TITER; ++i) {
@@ -642,8 +652,8 @@ __device__ int stage_tile(const MapView &m, const CellRange &c, WaveTile &t, con
       const bool act = tt < total;
       const int tq = act ? tt : 0;
       int row = 0;
-      for (int l = 0; l < nrows; ++l) row += (tq >= __shfl(inc, l));
-      const int src = __shfl(s, row) + (tq - __shfl(excl, row));
+      for (int l = 0; l < nrows; ++l) row += (tq >= __builtin_amdgcn_readlane(inc, l));
+      const int src = tq + __shfl(delta, row);
       if (act) {
         rx[i] = m.x[src];
         ry[i] = m.y[src];
@@ -662,8 +672,8 @@ __device__ int stage_tile(const MapView &m, const CellRange &c, WaveTile &t, con
       const float tt = px * f.dirx + py * f.diry;
       const float uu = py * f.dirx - px * f.diry;
       const bool keep = act && (inr || (tt >= f.t_lo && tt <= f.t_hi && fabsf(uu) <= f.u_max));
-      const unsigned long long mask = __ballot(keep);
-      in_range += __popcll(__ballot(inr));
+      const unsigned long long mask = ballot(keep);
+      in_range += __popcll(ballot(inr));
       if (keep) {
         const int pos = n + __popcll(mask & lanemask_lt());
         f2 v;
@@ -729,7 +739,7 @@ __device__ int median_count(const float *zb, int n, float h) {
       found = true;
     }
   }
-  const unsigned long long who = __ballot(found);
+  const unsigned long long who = ballot(found);
   const float zmed = who ? __shfl(mine, __ffsll((long long)who) - 1) : zb[0];
   int cnt = 0;
   for (int i = lane; i < n; i += WAVE) cnt += fabsf(zb[i] - zmed) > h;
@@ -752,7 +762,7 @@ __device__ __forceinline__ int median_count_lanes(float z, int n, float h, unsig
     const int top = 31 - __clz((int)diff);
     prefix = (top == 31) ? 0u : (key_lo & ~((2u << top) - 1u));
     for (int bit = top; bit >= 0; --bit) {
-      const unsigned long long ones = __ballot((key >> bit) & 1u);
+      const unsigned long long ones = ballot((key >> bit) & 1u);
       const unsigned long long zeros = alive & ~ones;
       const int c0 = __popcll(zeros);
       if (k < c0) {
@@ -765,7 +775,7 @@ __device__ __forceinline__ int median_count_lanes(float z, int n, float h, unsig
     }
   }
   const float zmed = key_float(prefix);
-  return __popcll(__ballot(lane < n && fabsf(z - zmed) > h));
+  return __popcll(ballot(lane < n && fabsf(z - zmed) > h));
 }
 
 // isCollision of one disc, candidates read from the tile.  n_out = points in the disc.
@@ -787,7 +797,7 @@ __device__ bool tile_disc_collides(WaveTile &t, int T, float qx, float qy, float
       const float d2 = dx * dx + dy * dy;
       hit = d2 <= r2;
     }
-    const unsigned long long mask = __ballot(hit);
+    const unsigned long long mask = ballot(hit);
     if (hit) {
       t.zb[n + __popcll(mask & lanemask_lt())] = z;
       zmin = fminf(zmin, z);
@@ -911,7 +921,7 @@ __device__ __forceinline__ void sweep_discs(const WaveTile &tile, int T, const f
       const f2 dd = d * d;
       const float d2 = dd.x + dd.y;
       const bool hit = valid && d2 <= r2;
-      cnt[k] += __popcll(__ballot(hit));
+      cnt[k] += __popcll(ballot(hit));
       const unsigned lo = hit ? zk : 0xFFFFFFFFu, hi = hit ? zk : 0u;
       kmn[k] = lo < kmn[k] ? lo : kmn[k];
       kmx[k] = hi > kmx[k] ? hi : kmx[k];
@@ -983,7 +993,11 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
   EDGE_CUT(1)  // geometry only
   int staged_in_range = 0;
   const int T = stage_tile(m, box, tile, cf, staged_in_range);
-  EDGE_CUT(2)  // + tile staging
+  if (TRG_EDGE_STAGE_CUT == 2) {  // + tile staging (keep its results alive)
+    o.status = EDGE_SEG + (T + staged_in_range > 1000000) +
+               (tile.z[lane] + tile.xy[lane].x + tile.xy[lane + 64].y == 12345.0f);
+    return o;
+  }
 
   unsigned long long hits = 0;
   const float ds = p.robot_size * 0.5f;
@@ -1061,7 +1075,7 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
                   z = tile.z[i];
                   hit = dd.x + dd.y <= r2;
                 }
-                const unsigned long long mask = __ballot(hit);
+                const unsigned long long mask = ballot(hit);
                 if (hit) tile.zb[nn + __popcll(mask & lanemask_lt())] = z;
                 nn += __popcll(mask);
               }
@@ -1094,7 +1108,7 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
           const f2 pt = tile.xy[i];
           keep = ellipse_point(ep, pt.x, pt.y, tile.z[i], mo);
         }
-        kept += __popcll(__ballot(keep));
+        kept += __popcll(ballot(keep));
       }
       if (TRG_EDGE_STAGE_CUT == 5) {  // + ellipse sweep
         o.status = EDGE_SEG + (mo.s_x + mo.s_y + mo.s_z + mo.s_xx + mo.s_xy + mo.s_xz + mo.s_yy +
