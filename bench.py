@@ -134,11 +134,13 @@ def main():
                 pass
             g = _G()
             g.xyz = eng.node_xyz("global")
+            t_st = time.perf_counter()
             (ids, _, _), nrec = tiled.stitch(rank, g, core, cols, rows, MOUNTAIN["expand_dist"],
                                              eng.edge_risk, dist, coll_dev)
             mine = int(((ids[:, 0] == rank).sum() + (ids[:, 2] == rank).sum())) if ids.size else 0
             stitch_info["cross_edges"] = int(ids.shape[0])
             stitch_info["boundary_records"] = nrec
+            stitch_info["ms_stitch_last"] = 1e3 * (time.perf_counter() - t_st)
             E += mine  # directed cross edges that end up in this tile's adjacency lists
         return V, E
 
@@ -226,6 +228,8 @@ def main():
                 "bfs_host_levels": st["bfs_host_levels"],
                 "bfs_max_spin": st["bfs_max_spin"], "ms_bfs_loop": st["ms_bfs_loop"],
                 "ms_deferred": st["ms_deferred"], "ms_set_map_total": st["ms_set_map_total"],
+                "map_nn_resolved": st["map_nn_resolved"], "map_nn_unresolved": st["map_nn_unresolved"],
+                "ms_stitch_rank0": stitch_info.get("ms_stitch_last", 0.0),
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -71,7 +71,7 @@ def allgatherv(arr, dist=None, device=None):
     n = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    counts = torch.cat(counts).cpu().tolist()  # one device round trip for all counts
     width = int(np.prod(arr.shape[1:])) if arr.ndim > 1 else 1
     pad = max(max(counts), 1)
     tdtype = torch.from_numpy(np.zeros(1, arr.dtype)).dtype
@@ -80,11 +80,8 @@ def allgatherv(arr, dist=None, device=None):
         buf[:arr.shape[0]] = torch.from_numpy(arr.reshape(arr.shape[0], width)).to(dev)
     outs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
-    res = []
-    for o, c in zip(outs, counts):
-        a = o[:c].cpu().numpy()
-        res.append(a.reshape((c,) + arr.shape[1:]))
-    return res
+    host = torch.stack(outs).cpu().numpy()  # one copy back for all ranks' payloads
+    return [host[k, :c].reshape((c,) + arr.shape[1:]) for k, c in enumerate(counts)]
 
 
 def cross_pairs(my_tile, records_per_tile, expand_dist):
@@ -98,10 +95,14 @@ def cross_pairs(my_tile, records_per_tile, expand_dist):
     d = np.float32(expand_dist)
     if mine.shape[0] == 0:
         return out
+    lo, hi = mine[:, :2].min(0) - 1.01 * d, mine[:, :2].max(0) + 1.01 * d
     for u in range(my_tile + 1, len(records_per_tile)):
         other = records_per_tile[u]
         if other.shape[0] == 0:
             continue
+        o_lo, o_hi = other[:, :2].min(0), other[:, :2].max(0)
+        if (o_lo > hi).any() or (o_hi < lo).any():
+            continue  # bounding boxes farther apart than expand_dist: no pair possible
         tree = cKDTree(other[:, :2].astype(np.float64))
         hits = tree.query_ball_point(mine[:, :2].astype(np.float64), r=float(expand_dist) * 1.001 + 1e-6)
         ia = np.repeat(np.arange(mine.shape[0]), [len(h) for h in hits])
@@ -172,15 +173,22 @@ def stitch(my_tile, graph, core, cols, rows, expand_dist, edge_risk, dist=None, 
     Returns (ids[k,4] int32, w[k], dist[k]) of ALL ranks' stitched edges, identical on every rank,
     and the number of boundary records exchanged."""
     bidx = boundary_nodes(graph.xyz, core, cols, rows, my_tile, expand_dist)
-    rec_xyz = np.ascontiguousarray(graph.xyz[bidx], dtype=np.float32)
-    all_idx = allgatherv(bidx, dist, device)
-    all_xyz = allgatherv(rec_xyz, dist, device)
-    if len(all_xyz) == 1:  # single process: nothing to stitch against
+    # exchange 1: boundary records (local id, x, y, z), 16 bytes each, one all-gather-v
+    rec = np.empty((bidx.shape[0], 4), np.float32)
+    rec[:, 0] = bidx.view(np.float32)
+    rec[:, 1:] = graph.xyz[bidx]
+    all_rec = allgatherv(rec, dist, device)
+    if len(all_rec) == 1:  # single process: nothing to stitch against
         z = np.zeros(0, np.float32)
         return (np.zeros((0, 4), np.int32), z, z), 0
+    all_idx = [np.ascontiguousarray(r[:, 0]).view(np.int32) for r in all_rec]
+    all_xyz = [np.ascontiguousarray(r[:, 1:]) for r in all_rec]
     ids, w, d = stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk)
-    g_ids = allgatherv(ids, dist, device)
-    g_w = allgatherv(w, dist, device)
-    g_d = allgatherv(d, dist, device)
-    return (np.concatenate(g_ids, 0), np.concatenate(g_w, 0), np.concatenate(g_d, 0)), \
-        int(sum(a.shape[0] for a in all_idx))
+    # exchange 2: the cross edges this tile owns (tile_a, id_a, tile_b, id_b, weight, dist), 24 bytes
+    out = np.empty((ids.shape[0], 6), np.int32)
+    out[:, :4] = ids
+    out[:, 4] = np.ascontiguousarray(w, dtype=np.float32).view(np.int32)
+    out[:, 5] = np.ascontiguousarray(d, dtype=np.float32).view(np.int32)
+    g = np.concatenate(allgatherv(out, dist, device), 0)
+    return (np.ascontiguousarray(g[:, :4]), np.ascontiguousarray(g[:, 4]).view(np.float32),
+            np.ascontiguousarray(g[:, 5]).view(np.float32)), int(sum(a.shape[0] for a in all_idx))
