@@ -132,7 +132,7 @@ constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, no
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
   BFS_CTR_V = 0, BFS_CTR_MNEXT = 1, BFS_CTR_NCAND = 2, BFS_CTR_NUNC = 3, BFS_CTR_ERR = 4,
-  BFS_CTR_NBPOOL = 5, BFS_CTR_NMAPTIE = 6, BFS_CTR_COUNT = 8
+  BFS_CTR_NBPOOL = 5, BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */, BFS_CTR_COUNT = 8
 };
 enum : int {
   BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
@@ -166,7 +166,7 @@ struct BfsDev {
   // uncertain slope gates for the host
   int *unc_list;
   float *unc_rec;
-  MapTieRec *mt_rec;  // MAPTIE_CAP records, count in ctrs[BFS_CTR_NMAPTIE]
+  MapTieRec *mt_rec;  // 2 x MAPTIE_CAP records (level parity), counts in ctrs[BFS_CTR_NMAPTIE + parity]
   // candidate hash of the level
   int *ht_key, *ht_val, *ht_slot;
   float *ht_x, *ht_y;
@@ -192,7 +192,8 @@ struct FinDev {
 void launch_bfs_insert_nodes(const BfsDev &B, int first, int count, hipStream_t s);
 void launch_bfs_sample(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
                        int table_bits, uint32_t seed, uint32_t epoch, const BfsDev &B, int count,
-                       DeviceCounters *ctr, hipStream_t s);
+                       DeviceCounters *ctr, hipStream_t s, const int *count_dev, int node_base,
+                       int parity);
 // classify + candidate scan/fill + speculative parent edges (ends where the host must look at
 // BFS_CTR_NUNC); flag / scan_tmp: scratch of count*S+1 and count*S/2048+4 ints
 void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int count, int *flag,

@@ -1717,14 +1717,18 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
                                                            float *sx, float *sy, float *sz,
                                                            DeviceCounters *ctr, const int *front,
                                                            const float *gnx, const float *gny,
-                                                           int *mt_count, MapTieRec *mt_rec) {
+                                                           int *mt_count, MapTieRec *mt_rec,
+                                                           const int *count_dev, int node_base) {
   __shared__ SampleLds L;
   __shared__ int r_col[SW];
   __shared__ float r_x[SW], r_y[SW], r_z[SW];
   __shared__ unsigned long long r_hits[SW];
   __shared__ int r_ties[SW];
   __shared__ int s_row[SBOX], row_off[SBOX + 1];
-  const int node = blockIdx.x;
+  // count_dev: the frontier size lives on the device (launch issued before the host knew it; the
+  // grid is an upper bound), node_base: first node of a follow-up launch
+  const int node = (int)blockIdx.x + node_base;
+  if (count_dev) count = min(count, *count_dev);
   if (node >= count) return;
   const int tid = threadIdx.x;
   const int w = tid >> 6;
@@ -1951,7 +1955,7 @@ void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, co
   hipLaunchKernelGGL(k_sample_nodes, dim3(count), dim3(SW * WAVE), 0, s, m, p, cos_t, sin_t,
                      table_bits, seed, epoch, node_xy, node_id, count, n_acc, n_draws, sx, sy, sz,
                      ctr, (const int *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                     mt_count, mt_rec);
+                     mt_count, mt_rec, (const int *)nullptr, 0);
 }
 void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieSet *d_out,
                          hipStream_t s) {
