@@ -162,6 +162,7 @@ struct BfsDev {
   // per candidate
   int *cand_slot, *c_status, *c_outcome, *c_target, *c_newid;
   int *newnode_slot;  // slot of the sample that created node V0 + k in the current level
+  int *blk_tot;       // per 256-candidate group: created | valid << 16 (k_bfs_resolve -> k_bfs_commit)
   float *mid, *c_weight, *c_dist;
   // uncertain slope gates for the host
   int *unc_list;
