@@ -126,8 +126,6 @@ void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, i
                        DeviceCounters *ctr, hipStream_t s);
 
 // ---- device-resident BFS (trg_bfs.inc) ------------------------------------------------------------
-constexpr int BFS_NBMAX = 40;      // pool entries per sample slot (static segments + overflow)
-constexpr int BFS_NB_STATIC = 24;  // list length served from a candidate's own fixed segment
 constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, nodes are >= robot_size apart)
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
@@ -155,10 +153,8 @@ struct BfsDev {
   // per frontier node
   int *n_acc, *n_draws;
   // per sample slot (fcap * S)
-  float *sx, *sy, *sz, *d0sq, *nb_d2;
-  int *nn0, *cls, *cand_off, *nb_cnt, *nb_off, *nb_idx;
-  long long nb_pool;  // entries in nb_idx / nb_d2
-  int nb_static;      // first entry of the shared overflow region
+  float *sx, *sy, *sz, *d0sq;
+  int *nn0, *cls, *cand_off;
   // per candidate
   int *cand_slot, *c_status, *c_outcome, *c_target, *c_newid;
   int *newnode_slot;  // slot of the sample that created node V0 + k in the current level
