@@ -1631,7 +1631,7 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
   const int cx0 = max(c.cx0 - L.bx0, 0), cx1 = min(c.cx1 - L.bx0, L.ncols - 1);
   const int cy0 = max(c.cy0 - L.by0, 0), cy1 = min(c.cy1 - L.by0, L.nrows - 1);
   int n = 0;
-  float zmin = FLT_MAX, zmax = -FLT_MAX;
+  unsigned kmn = 0xFFFFFFFFu, kmx = 0u;  // smallest / largest z key among this lane's hits
   float best_d2 = FLT_MAX, best_z = 0.0f;
   int best_perm = INT_MAX;
   bool lane_tie = false;
@@ -1648,12 +1648,13 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
         d2 = dx * dx + dy * dy;
         hit = d2 <= r2;
       }
-      const unsigned long long mask = __ballot(hit);
+      const unsigned long long mask = ballot(hit);
       if (hit) {
         const int pos = n + __popcll(mask & lanemask_lt());
         if (pos < SHCAP) zb[pos] = z;
-        zmin = fminf(zmin, z);
-        zmax = fmaxf(zmax, z);
+        const unsigned zk = float_key(z);
+        kmn = zk < kmn ? zk : kmn;
+        kmx = zk > kmx ? zk : kmx;
         const int pm = L.perm[i];
         if (d2 == best_d2) lane_tie = true;
         if (d2 < best_d2) lane_tie = false;
@@ -1673,28 +1674,25 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
   out.nn_tie = 0;
   out.nn_d2 = 0.0f;
   if (n == 0) return out;
-  float wd = best_d2, wz = best_z;
-  int wp = best_perm;
-#pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-    const float od = __shfl_xor(wd, msk);
-    const float oz = __shfl_xor(wz, msk);
-    const int op = __shfl_xor(wp, msk);
-    zmin = fminf(zmin, __shfl_xor(zmin, msk));
-    zmax = fmaxf(zmax, __shfl_xor(zmax, msk));
-    if (od < wd || (od == wd && op < wp)) {
-      wd = od;
-      wz = oz;
-      wp = op;
-    }
-  }
-  out.nn_z = wz;
-  out.nn_d2 = wd;
-  out.nn_tie =
-      __ballot(best_perm != INT_MAX && best_d2 == wd && (best_perm != wp || lane_tie)) != 0ull;
+  // nearest point: smallest distance (d2 >= 0, so its bit pattern orders like the value), then the
+  // smallest original index among the lanes that hold it -- DPP reductions, no LDS round trips
+  const unsigned dkey = __float_as_uint(best_d2);
+  const unsigned wdk = wave_reduce_key<true>(dkey);
+  const bool holds = best_perm != INT_MAX && dkey == wdk;
+  const unsigned wp = wave_reduce_key<true>(holds ? (unsigned)best_perm : 0xFFFFFFFFu);
+  const unsigned long long who = ballot(holds && (unsigned)best_perm == wp);
+  out.nn_z = __shfl(best_z, __ffsll((long long)who) - 1);
+  out.nn_d2 = __uint_as_float(wdk);
+  out.nn_tie = ballot(holds && ((unsigned)best_perm != wp || lane_tie)) != 0ull;
+  const unsigned klo = wave_reduce_key<true>(kmn), khi = wave_reduce_key<false>(kmx);
   // every |z - z_med| <= zmax - zmin (rounding is monotone), so a flat disc needs no median
-  if (!(zmax - zmin <= h)) {
-    if (n <= SHCAP) {
+  if (!(key_float(khi) - key_float(klo) <= h)) {
+    if (n <= WAVE) {
+      wave_lds_sync();
+      const float zl = zb[lane < n ? lane : 0];
+      out.cnt = median_count_lanes(zl, n, h, klo, khi);
+      wave_lds_sync();
+    } else if (n <= SHCAP) {
       wave_lds_sync();
       out.cnt = median_count(zb, n, h);
       wave_lds_sync();
@@ -1802,11 +1800,22 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
   int n_acc = 0, rejects = 0, draws = 0;
   unsigned long long hits = 0;
   int ties = 0;
+  // the table entries of a round are fetched one round ahead (a full round always consumes
+  // exactly SW draws, so the next round's trial numbers are known)
+  float c_next, s_next;
+  {
+    const uint32_t k = sample_hash(seed, epoch, id, (uint32_t)w) >> (32 - table_bits);
+    c_next = cos_t[k];
+    s_next = sin_t[k];
+  }
   while (n_acc < S && rejects <= max_trial_sample) {
-    const uint32_t t = (uint32_t)(draws + w);
-    const uint32_t k = sample_hash(seed, epoch, id, t) >> (32 - table_bits);
-    const float qx = px + p.expand_dist * cos_t[k];
-    const float qy = py + p.expand_dist * sin_t[k];
+    const float qx = px + p.expand_dist * c_next;
+    const float qy = py + p.expand_dist * s_next;
+    {
+      const uint32_t k = sample_hash(seed, epoch, id, (uint32_t)(draws + SW + w)) >> (32 - table_bits);
+      c_next = cos_t[k];
+      s_next = sin_t[k];
+    }
     Disc d;
     bool done_tile = false;
     if (use_tile) {
