@@ -112,7 +112,10 @@ typedef struct TrgStats {
   uint64_t bytes_spec_kernel;     /* k_spec_edges (speculative parent edges) */
   uint64_t bytes_edge_kernel;     /* k_edges (deferred wireEdge evaluations) */
   uint64_t bytes_index_build;
-  /* device time per kernel, milliseconds, measured with hipEvents on the launch stream */
+  /* device time per kernel, milliseconds, measured with hipEvents on the launch stream.  Inside the
+   * device-resident BFS the sampling and speculative-edge kernels are timed on every 8th level
+   * only (an event pair costs ~12 us of stream time per level) and the sums are scaled by
+   * launches / timed launches; the deferred edge evaluations are timed in full. */
   double ms_index_build;
   double ms_sample_kernel;
   double ms_spec_kernel;
