@@ -201,8 +201,11 @@ constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-reside
 void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
                         int V0, int ncand_bound, hipStream_t s);
 void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
-void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, long long base, int count,
+void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, const int *list, int count,
                        DeviceCounters *ctr, hipStream_t s);
+void launch_first_insert(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
+void launch_calls_select(const FinDev &F, const BfsDev &B, long long ncalls, int round, int *flag,
+                         int *off, int *scan_tmp, int *list, hipStream_t s);
 void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
 void launch_fin_scatter_sort(const FinDev &F, const BfsDev &B, long long ncalls, int V, hipStream_t s);
 void launch_fin_clean(const FinDev &F, const BfsDev &B, const int *new2old, const int *old2new, int Vn,
