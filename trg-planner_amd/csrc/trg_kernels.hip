@@ -1603,7 +1603,10 @@ __global__ __launch_bounds__(256) void k_edge_finish(const float *mid, int count
   dist[q] = r[2];
 }
 
-constexpr int SW = 8;  // waves per block in the sampling kernel = trials evaluated per round
+#ifndef TRG_SW
+#define TRG_SW 8
+#endif
+constexpr int SW = TRG_SW;  // waves per block in the sampling kernel = trials evaluated per round
 
 // Block-shared neighbour tile of the sampling kernel.  Every draw of a node lies on the circle of
 // radius expand_dist around it, so all its collision discs fall inside one (2*(d+r))^2 box: the
@@ -1631,7 +1634,6 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
   const int cx0 = max(c.cx0 - L.bx0, 0), cx1 = min(c.cx1 - L.bx0, L.ncols - 1);
   const int cy0 = max(c.cy0 - L.by0, 0), cy1 = min(c.cy1 - L.by0, L.nrows - 1);
   int n = 0;
-  unsigned kmn = 0xFFFFFFFFu, kmx = 0u;  // smallest / largest z key among this lane's hits
   float best_d2 = FLT_MAX, best_z = 0.0f;
   int best_perm = INT_MAX;
   bool lane_tie = false;
@@ -1652,9 +1654,6 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
       if (hit) {
         const int pos = n + __popcll(mask & lanemask_lt());
         if (pos < SHCAP) zb[pos] = z;
-        const unsigned zk = float_key(z);
-        kmn = zk < kmn ? zk : kmn;
-        kmx = zk > kmx ? zk : kmx;
         const int pm = L.perm[i];
         if (d2 == best_d2) lane_tie = true;
         if (d2 < best_d2) lane_tie = false;
@@ -1684,22 +1683,24 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
   out.nn_z = __shfl(best_z, __ffsll((long long)who) - 1);
   out.nn_d2 = __uint_as_float(wdk);
   out.nn_tie = ballot(holds && ((unsigned)best_perm != wp || lane_tie)) != 0ull;
+  if (n > SHCAP) {
+    out.cnt = -1;  // caller falls back to the global-memory query
+    return out;
+  }
+  // z range of the hits, from the compacted hit buffer (one value per lane in the usual case)
+  wave_lds_sync();
+  const float zl = zb[lane < n ? lane : 0];
+  unsigned kmn = 0xFFFFFFFFu, kmx = 0u;
+  for (int i = lane; i < n; i += WAVE) {
+    const unsigned zk = float_key(i == lane ? zl : zb[i]);
+    kmn = zk < kmn ? zk : kmn;
+    kmx = zk > kmx ? zk : kmx;
+  }
   const unsigned klo = wave_reduce_key<true>(kmn), khi = wave_reduce_key<false>(kmx);
   // every |z - z_med| <= zmax - zmin (rounding is monotone), so a flat disc needs no median
-  if (!(key_float(khi) - key_float(klo) <= h)) {
-    if (n <= WAVE) {
-      wave_lds_sync();
-      const float zl = zb[lane < n ? lane : 0];
-      out.cnt = median_count_lanes(zl, n, h, klo, khi);
-      wave_lds_sync();
-    } else if (n <= SHCAP) {
-      wave_lds_sync();
-      out.cnt = median_count(zb, n, h);
-      wave_lds_sync();
-    } else {
-      out.cnt = -1;  // caller falls back to the global-memory query
-    }
-  }
+  if (!(key_float(khi) - key_float(klo) <= h))
+    out.cnt = (n <= WAVE) ? median_count_lanes(zl, n, h, klo, khi) : median_count(zb, n, h);
+  wave_lds_sync();
   return out;
 }
 
@@ -1718,8 +1719,7 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
                                                            int *mt_count, MapTieRec *mt_rec,
                                                            const int *count_dev, int node_base) {
   __shared__ SampleLds L;
-  __shared__ int r_col[SW];
-  __shared__ float r_x[SW], r_y[SW], r_z[SW];
+  __shared__ int r_col[2][SW];
   __shared__ unsigned long long r_hits[SW];
   __shared__ int r_ties[SW];
   __shared__ int s_row[SBOX], row_off[SBOX + 1];
@@ -1797,9 +1797,10 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
 
   const int S = p.sample_num;
   const int max_trial_sample = 1000;
-  int n_acc = 0, rejects = 0, draws = 0;
+  int n_acc = 0, rejects = 0, draws = 0, round = 0;
   unsigned long long hits = 0;
   int ties = 0;
+  const int wu = __builtin_amdgcn_readfirstlane(w);  // the wave index as a scalar
   // the table entries of a round are fetched one round ahead (a full round always consumes
   // exactly SW draws, so the next round's trial numbers are known)
   float c_next, s_next;
@@ -1826,47 +1827,48 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
     // disc with more hits than that selects the median by re-reading the map)
     if (!done_tile)
       d = disc_query<true>(m, qx, qy, p.robot_size, p.height_threshold, L.zb[w], ctr, SHCAP);
-    if (lane == 0) {
-      const bool in_core = qx >= p.core_x0 && qx < p.core_x1 && qy >= p.core_y0 && qy < p.core_y1;
-      r_col[w] = (disc_collides(d, p.collision_threshold) || !in_core) ? 1 : 0;
-      r_x[w] = qx;
-      r_y[w] = qy;
-      r_z[w] = d.nn_z;
-    }
+    const bool in_core = qx >= p.core_x0 && qx < p.core_x1 && qy >= p.core_y0 && qy < p.core_y1;
+    const bool collides = disc_collides(d, p.collision_threshold) || !in_core;
+    int *colbuf = r_col[round & 1];  // double-buffered: one barrier per round
+    if (lane == 0) colbuf[w] = collides ? 1 : 0;
     hits += (unsigned long long)d.n;
     __syncthreads();
-    // in-order acceptance; every thread runs the same scalar loop so control stays uniform
+    // In-order acceptance (trg.cpp:386-402).  The round's reject flags are packed into one mask so
+    // that the sequential loop runs on the scalar unit; the wave whose draw is accepted stores it.
+    const unsigned long long colmask = ballot(lane < SW && colbuf[lane < SW ? lane : 0] != 0);
+    int my_slot = -1;
     for (int i = 0; i < SW; ++i) {
       if (n_acc >= S || rejects > max_trial_sample) break;
       draws++;
-      if (r_col[i]) {
+      if ((colmask >> i) & 1ull) {
         rejects++;
       } else {
-        if (threadIdx.x == 0) {
-          const int slot = node * S + n_acc;
-          sx[slot] = r_x[i];
-          sy[slot] = r_y[i];
-          sz[slot] = r_z[i];
-        }
-        if (i == w && d.nn_tie) {
-          // the accepted sample's elevation hangs on a nearest-point tie: tell the host
-          ties++;
-          if (lane == 0 && mt_count) {
-            const int k = atomicAdd(mt_count, 1);
-            if (k < MAPTIE_CAP) {
-              MapTieRec rec;
-              rec.slot = node * S + n_acc;
-              rec.qx = qx;
-              rec.qy = qy;
-              rec.d2 = d.nn_d2;
-              mt_rec[k] = rec;
-            }
-          }
-        }
+        if (i == wu) my_slot = n_acc;
         n_acc++;
       }
     }
-    __syncthreads();
+    if (my_slot >= 0 && lane == 0) {
+      const int slot = node * S + my_slot;
+      sx[slot] = qx;
+      sy[slot] = qy;
+      sz[slot] = d.nn_z;
+      if (d.nn_tie) {
+        // the accepted sample's elevation hangs on a nearest-point tie: tell the host
+        ties++;
+        if (mt_count) {
+          const int k = atomicAdd(mt_count, 1);
+          if (k < MAPTIE_CAP) {
+            MapTieRec rec;
+            rec.slot = slot;
+            rec.qx = qx;
+            rec.qy = qy;
+            rec.d2 = d.nn_d2;
+            mt_rec[k] = rec;
+          }
+        }
+      }
+    }
+    round++;
   }
   if (threadIdx.x == 0) {
     n_acc_out[node] = n_acc;
