@@ -224,7 +224,12 @@ TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size
 /* "replay" = "device" (default: BFS, dedupe and CSR on the GPU when expandGraph's step 3 is off,
  * trg.cpp:429) | "host" (sequential replay on the host, the only mode for step-3 configs);
  * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot).  Both modes give identical
- * graphs; the env var TRG_REPLAY=host sets the default. */
+ * graphs; the env var TRG_REPLAY=host sets the default.  Test hooks (never change results):
+ * "debug_tie_every" = n (treat every n-th BFS level as tie-affected -> host level replay),
+ * "debug_gate_margin" = x (widen the band of slope gates left to the host's libm),
+ * "debug_spec_bound" = n (cap the speculative next-level sampling launch at n nodes -> top-up
+ * launches), "debug_fallback_level" = n (the device BFS declines at level n -> whole-build host
+ * replay). */
 TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value);
 /* Tiled builds (multi-GPU; an extension, not a reference interface): restrict
  * node creation to the core region [x0,x1) x [y0,y1) -- a sample outside it counts as a rejected

@@ -303,3 +303,41 @@ def test_uncertain_slope_gates_are_decided_by_host_libm(oa, mountain_small, repl
     assert o.counters()["wire_gate"] > 0
     assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL, allow_weight_outliers=3)
     assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)
+
+
+def test_speculative_sampling_bound_and_top_up(oa, mountain_small):
+    """The next BFS level is sampled before the host knows its size: the launch is an upper bound
+    and a follow-up launch covers the rest when the frontier outgrew it.  With the bound capped at
+    3 nodes (test hook) nearly every level needs the follow-up; the graph must not change."""
+    prm = dict(oa.MOUNTAIN, sample_num=9)
+    e, o = _build_both(oa, prm, mountain_small, [15.0, 15.0, 0.0], seed=5)
+    ref = e.graph("global")
+    e2 = _engine(prm)
+    e2.set_sampler(5, 16)
+    e2.set_option("debug_spec_bound", 3)
+    e2.set_global_map(mountain_small)
+    e2.init_graph([15.0, 15.0, 0.0])
+    assert e2.stats()["used_device_bfs"] == 1, e2.fallback_reason
+    assert_graph_equal(e2.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)
+    assert_graph_equal(e2.graph("global"), ref, 0.0)
+    for k in ("trials", "samples", "created_nodes", "invalid_nodes"):
+        assert e2.stats()[k] == e.stats()[k], k
+
+
+def test_device_bfs_declining_falls_back_to_the_host_replay(oa, mountain_small):
+    """Capacity overflows make the device-resident BFS decline; the engine then redoes the build
+    with the sequential host replay.  Forced here at level 6 (test hook)."""
+    prm = dict(oa.MOUNTAIN)
+    e = _engine(prm)
+    e.set_sampler(7, 16)
+    e.set_option("debug_fallback_level", 6)
+    e.set_global_map(mountain_small)
+    e.init_graph([15.0, 15.0, 0.0])
+    st = e.stats()
+    assert st["used_device_bfs"] == 0 and st["bfs_fallbacks"] == 1, st
+    assert "declined on request" in e.fallback_reason
+    o = oa.Oracle(**prm)
+    o.set_sampler(7, 0, 16)
+    o.set_global_map(mountain_small)
+    assert o.init_graph([15.0, 15.0, 0.0])
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)

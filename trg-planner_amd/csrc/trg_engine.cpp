@@ -328,6 +328,8 @@ struct TrgEngine {
   bool host_grid_valid = true;   // e->grid holds the current node set
   bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
   int debug_tie_every = 0;       // test hook: treat every n-th BFS level as tie-affected
+  int debug_spec_bound = 0;      // test hook: cap the speculative sampling launch at n nodes
+  int debug_fallback_level = -1; // test hook: the device BFS declines at this level
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
@@ -1752,6 +1754,14 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_tie_every") {
     e->debug_tie_every = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "debug_spec_bound") {
+    e->debug_spec_bound = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "debug_fallback_level") {
+    e->debug_fallback_level = atoi(v.c_str());
     return TRG_OK;
   }
   if (k == "keep_preclean") {
