@@ -173,8 +173,6 @@ struct BfsDev {
   float *call_w, *call_dist;
   // counters
   int *ctrs;
-  int *host_ctrs;  // pinned host mirror: BFS_CTR_COUNT counters + a stamp (written by k_bfs_emit)
-  int *done_ctr;   // workgroups of k_bfs_emit that have finished
   unsigned long long *stats64;  // draws, samples, created, invalid, spec evaluations
 };
 
@@ -200,9 +198,8 @@ void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int co
                         hipEvent_t spec_end);
 // neighbour lists + resolve + call emission
 constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-resident (<= 512 groups)
-// stamp: written to host_ctrs[BFS_CTR_COUNT] after the level's counters (the host polls it)
 void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
-                        int V0, int ncand_bound, int stamp, hipStream_t s);
+                        int V0, int ncand_bound, hipStream_t s);
 void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
 void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, const int *list, int count,
                        DeviceCounters *ctr, hipStream_t s);
