@@ -1364,11 +1364,10 @@ __global__ __launch_bounds__(256) void k_scatter(const float *xyz, size_t n, siz
 
 // The atomic rank above is arrival order; sorting every cell by original index makes the index
 // (and therefore every fp64 accumulation order downstream) independent of scheduling.
-__global__ __launch_bounds__(256) void k_cell_sort(int ncell, const int *cell_start, float *x,
-                                                   float *y, float *z, int *perm) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncell) return;
-  const int s = cell_start[c], e = cell_start[c + 1];
+constexpr int CSORT_CAP = 3072;  // points of 256 consecutive cells staged in LDS (48 KB)
+
+__device__ __forceinline__ void cell_insertion_sort(float *x, float *y, float *z, int *perm, int s,
+                                                    int e) {
   for (int i = s + 1; i < e; ++i) {
     const int kp = perm[i];
     const float kx = x[i], ky = y[i], kz = z[i];
@@ -1384,6 +1383,38 @@ __global__ __launch_bounds__(256) void k_cell_sort(int ncell, const int *cell_st
     x[j + 1] = kx;
     y[j + 1] = ky;
     z[j + 1] = kz;
+  }
+}
+
+// A workgroup owns 256 consecutive cells, i.e. one contiguous range of the sorted arrays: it is
+// staged in LDS with coalesced loads, every thread sorts its own cell there, and the range is
+// written back coalesced (ranges too long for LDS are sorted in place in global memory).
+__global__ __launch_bounds__(256) void k_cell_sort(int ncell, const int *cell_start, float *x,
+                                                   float *y, float *z, int *perm) {
+  __shared__ float lx[CSORT_CAP], ly[CSORT_CAP], lz[CSORT_CAP];
+  __shared__ int lp[CSORT_CAP];
+  const int c0 = blockIdx.x * blockDim.x;
+  const int c = c0 + threadIdx.x;
+  const int p0 = cell_start[c0], p1 = cell_start[min(c0 + (int)blockDim.x, ncell)];
+  const int n = p1 - p0;
+  if (n > CSORT_CAP) {
+    if (c < ncell) cell_insertion_sort(x, y, z, perm, cell_start[c], cell_start[c + 1]);
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    lx[i] = x[p0 + i];
+    ly[i] = y[p0 + i];
+    lz[i] = z[p0 + i];
+    lp[i] = perm[p0 + i];
+  }
+  __syncthreads();
+  if (c < ncell) cell_insertion_sort(lx, ly, lz, lp, cell_start[c] - p0, cell_start[c + 1] - p0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    x[p0 + i] = lx[i];
+    y[p0 + i] = ly[i];
+    z[p0 + i] = lz[i];
+    perm[p0 + i] = lp[i];
   }
 }
 
