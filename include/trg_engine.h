@@ -187,6 +187,16 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path);
  * max_points x 3 floats; info->num_points is the full length. */
 TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goal_xyz[3],
                           float *path_xyz, int32_t max_points, TrgPathInfo *info);
+/* m consecutive planSafePath calls in one boundary crossing (reference: the loop over start/goal
+ * pairs of python/examples/run_trg_planner.py:35-43).  Exactly the results
+ * of calling trg_engine_plan m times in order (the goal state left behind is that of the last
+ * query).  path_xyz: room for path_cap points in total; query k's points are
+ * [offsets[k], offsets[k+1]) (offsets has m + 1 entries); a query without a path has an empty
+ * range and infos[k].num_points == 0; a path that no longer fits is truncated (num_points keeps
+ * its full length). */
+TrgStatus trg_engine_plan_batch(TrgEngine *e, const float *starts_xy, const float *goals_xyz,
+                                size_t m, float *path_xyz, int32_t path_cap, int32_t *offsets,
+                                TrgPathInfo *infos);
 /* reference: TRG::checkReadched (sic) trg.cpp:567-574 / TRG::checkReplan trg.cpp:576-601; 1 = true */
 int32_t trg_engine_check_reached(TrgEngine *e, const float pos_xy[2]);
 int32_t trg_engine_check_replan(TrgEngine *e, const float pos_xy[2], const float *path_xyz,

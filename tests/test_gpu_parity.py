@@ -212,6 +212,32 @@ def test_plan_parity(oa, mountain_gentle):
         assert np.array_equal(re_.view(np.uint32), ro.view(np.uint32))
 
 
+def test_plan_batch_equals_consecutive_plans(oa, mountain_gentle):
+    """trg_engine_plan_batch = m planSafePath calls in one boundary crossing (the loop over
+    start/goal pairs of the reference's run_trg_planner.py:35-43), including a query without a path
+    and a truncated output buffer."""
+    prm = dict(oa.MOUNTAIN)
+    e, o = _build_both(oa, prm, mountain_gentle, [15.0, 15.0, 0.0], seed=3)
+    rng = np.random.default_rng(4)
+    starts = rng.uniform(3, 27, (8, 2)).astype(np.float32)
+    goals = np.concatenate([rng.uniform(3, 27, (8, 2)), np.zeros((8, 1))], 1).astype(np.float32)
+    single = [e.plan(s, g) for s, g in zip(starts, goals)]
+    batch = e.plan_batch(starts, goals)
+    assert len(batch) == 8
+    for (ps, is_), (pb, ib) in zip(single, batch):
+        assert np.array_equal(ps.view(np.uint32), pb.view(np.uint32))
+        assert (is_.num_points, is_.direct_dist, is_.path_length, is_.avg_risk) == \
+               (ib.num_points, ib.direct_dist, ib.path_length, ib.avg_risk)
+    for (pb, ib), (s, g) in zip(batch, zip(starts, goals)):
+        po, io = o.plan(s, g)
+        assert np.array_equal(pb.view(np.uint32), po.view(np.uint32))
+    # a buffer that only holds the first path and a half: later ranges are cut, lengths are kept
+    cap = batch[0][0].shape[0] + batch[1][0].shape[0] // 2
+    cut = e.plan_batch(starts, goals, path_cap=cap)
+    assert cut[0][0].shape == batch[0][0].shape and cut[1][0].shape[0] == cap - batch[0][0].shape[0]
+    assert cut[2][0].shape[0] == 0 and cut[2][1].num_points == batch[2][1].num_points
+
+
 def test_repeated_builds_are_identical(oa, mountain_small):
     """Same engine, same inputs, twice: the graph (including the container-order renumbering of
     cleanGraph, which depends on the hash table's bucket history) must match an oracle that went

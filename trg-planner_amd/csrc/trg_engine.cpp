@@ -2188,6 +2188,27 @@ TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goa
   return e->fail(TRG_ERR_NOT_FOUND, "no path");
 }
 
+TrgStatus trg_engine_plan_batch(TrgEngine *e, const float *starts_xy, const float *goals_xyz,
+                                size_t m, float *path_xyz, int32_t path_cap, int32_t *offsets,
+                                TrgPathInfo *infos) {
+  if (!e || !offsets || (m && (!starts_xy || !goals_xyz || !infos)))
+    return TRG_ERR_INVALID_ARG;
+  if (path_cap < 0 || (path_cap > 0 && !path_xyz)) return e->fail(TRG_ERR_INVALID_ARG, "path buffer");
+  int32_t used = 0;
+  offsets[0] = 0;
+  for (size_t k = 0; k < m; ++k) {
+    const int32_t room = path_cap - used;
+    const TrgStatus st = trg_engine_plan(e, starts_xy + 2 * k, goals_xyz + 3 * k,
+                                         path_xyz ? path_xyz + 3 * (size_t)used : nullptr, room,
+                                         &infos[k]);
+    if (st != TRG_OK && st != TRG_ERR_NOT_FOUND) return st;
+    if (st == TRG_ERR_NOT_FOUND) infos[k].num_points = 0;
+    used += std::min<int32_t>(infos[k].num_points, room);
+    offsets[k + 1] = used;
+  }
+  return TRG_OK;
+}
+
 // reference: TRG::checkReadched (sic) trg.cpp:567-574 and TRG::checkReplan trg.cpp:576-601
 int32_t trg_engine_check_reached(TrgEngine *e, const float pos_xy[2]) {
   if (!e || !pos_xy) return 0;

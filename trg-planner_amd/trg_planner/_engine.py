@@ -82,7 +82,7 @@ EXPORTS = [
     "trg_engine_is_frontier_batch", "trg_engine_get_stats", "trg_engine_get_sampler_table",
     "trg_engine_debug_map_index", "trg_engine_set_option", "trg_engine_fallback_reason",
     "trg_engine_check_reached", "trg_engine_check_replan", "trg_engine_set_tile",
-    "trg_engine_voxel_filter",
+    "trg_engine_voxel_filter", "trg_engine_plan_batch",
 ]
 
 
@@ -135,6 +135,8 @@ def load_library():
     L.trg_engine_plan.argtypes = [vp, fp, fp, fp, C.c_int32, C.POINTER(TrgPathInfo)]
     L.trg_engine_refine_path.argtypes = [fp, C.c_int32, fp, C.c_int32]
     L.trg_engine_refine_path.restype = C.c_int32
+    L.trg_engine_plan_batch.argtypes = [vp, fp, fp, C.c_size_t, fp, C.c_int32,
+                                        C.POINTER(C.c_int32), C.POINTER(TrgPathInfo)]
     L.trg_engine_voxel_filter.argtypes = [vp, fp, C.c_size_t, C.c_size_t, C.c_float, fp,
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     L.trg_engine_is_collision_batch.argtypes = [vp, C.c_int, C.c_float, fp, C.c_size_t, ip, ip, ip]
@@ -309,6 +311,18 @@ class Engine:
             return np.empty((0, 3), np.float32), info
         self._chk(st)
         return path[:info.num_points].copy(), info
+
+    def plan_batch(self, starts2d, goals3d, path_cap=200000):
+        """m consecutive planSafePath calls in one boundary crossing -> list of (path, info)."""
+        s = np.ascontiguousarray(starts2d, dtype=np.float32).reshape(-1, 2)
+        g = np.ascontiguousarray(goals3d, dtype=np.float32).reshape(-1, 3)
+        m = s.shape[0]
+        path = np.empty((path_cap, 3), np.float32)
+        off = np.zeros(m + 1, np.int32)
+        infos = (TrgPathInfo * max(m, 1))()
+        self._chk(self.L.trg_engine_plan_batch(self.h, _f(s), _f(g), m, _f(path), path_cap,
+                                               off.ctypes.data_as(C.POINTER(C.c_int32)), infos))
+        return [(path[off[k]:off[k + 1]].copy(), infos[k]) for k in range(m)]
 
     def check_reached(self, pos2d):
         p = np.ascontiguousarray(pos2d, dtype=np.float32)
