@@ -1789,11 +1789,26 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
     }
     __syncthreads();
     if (tid == 0) {
+      // Every trial disc lies within R = d + r of the node: of each cell row only the columns that
+      // such a disc can reach are staged (the corners of the box are never read).  The bounds are
+      // conservative by millimetres; which points a disc accepts is decided by the exact test.
+      const float R = (p.expand_dist + p.robot_size) * 1.002f + 2e-3f;
+      const float g = 1.0f / m.inv_g;
       int acc = 0;
       for (int row = 0; row < nrows; ++row) {
-        s_row[row] = L.cs[row][0];
+        const float yc = m.y0 + ((float)(box.cy0 + row) + 0.5f) * g;
+        const float dy = fmaxf(fabsf(yc - py) - 0.5f * g - 2e-3f, 0.0f);
+        int c_lo = 0, c_hi = -1;  // empty row
+        if (dy < R) {
+          const float hx = sqrtf(R * R - dy * dy) + 2e-3f;
+          c_lo = max(cell_coord(px - hx, m.x0, m.inv_g, m.W) - box.cx0, 0);
+          c_hi = min(cell_coord(px + hx, m.x0, m.inv_g, m.W) - box.cx0, ncols - 1);
+        }
+        const int a = c_hi >= c_lo ? L.cs[row][c_lo] : L.cs[row][0];
+        const int b = c_hi >= c_lo ? L.cs[row][c_hi + 1] : L.cs[row][0];
+        s_row[row] = a;
         row_off[row] = acc;
-        acc += L.cs[row][ncols] - L.cs[row][0];
+        acc += b - a;
       }
       row_off[nrows] = acc;
       L.total = acc;
@@ -1821,7 +1836,9 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
     __syncthreads();
     if (tid < ncs) {
       const int row = tid / (ncols + 1), col = tid - row * (ncols + 1);
-      L.cs[row][col] = row_off[row] + (L.cs[row][col] - s_row[row]);
+      // cells left / right of the staged columns are empty ranges at the row's start / end
+      const int len = row_off[row + 1] - row_off[row];
+      L.cs[row][col] = row_off[row] + min(max(L.cs[row][col] - s_row[row], 0), len);
     }
     __syncthreads();
   }
