@@ -306,6 +306,7 @@ struct TrgEngine {
   static constexpr int NCHUNK = 3;
   static constexpr int CHUNK_MAX = 4096;
   Chunk chunks[NCHUNK];
+  Chunk root_chunk;  // samples + speculative edges of updateGraph's expansion roots, fetched in bulk
   static constexpr int NEBATCH = 3;
   static constexpr int EBATCH_MAX = 1 << 16;
   EdgeBatch ebatches[NEBATCH];
@@ -966,7 +967,11 @@ TrgStatus ensure_chunks(TrgEngine *e) {
   if (e->chunk_S == S && e->chunks[0].done) return TRG_OK;
   const size_t cmax = TrgEngine::CHUNK_MAX;
   const size_t slots = cmax * (size_t)std::max(S, 1);
-  for (Chunk &c : e->chunks) {
+  Chunk *all_chunks[TrgEngine::NCHUNK + 1];
+  for (int i = 0; i < TrgEngine::NCHUNK; ++i) all_chunks[i] = &e->chunks[i];
+  all_chunks[TrgEngine::NCHUNK] = &e->root_chunk;
+  for (Chunk *cp : all_chunks) {
+    Chunk &c = *cp;
     if (!c.done) {
       HIPCHK(e, hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
       HIPCHK(e, hipEventCreate(&c.t0));
@@ -1038,6 +1043,16 @@ TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
   e->stats.launches_sample_kernel++;
   e->stats.launches_spec_kernel++;
   return TRG_OK;
+}
+
+// the same launch sequence for an explicit list of node ids (the roots of updateGraph's expansions)
+TrgStatus submit_nodes(TrgEngine *e, Chunk &c, const int *ids, int count) {
+  std::vector<int> saved;
+  saved.swap(e->queue);
+  e->queue.assign(ids, ids + count);
+  const TrgStatus st = submit_chunk(e, c, 0, count);
+  e->queue.swap(saved);
+  return st;
 }
 
 TrgStatus wait_chunk(TrgEngine *e, Chunk &c) {
@@ -1182,7 +1197,9 @@ void apply_calls(TrgEngine *e, size_t from) {
 // BFS expansion from the node `ref_id`, replaying trg.cpp:372-454 with GPU results.
 // `applied` is the index of the first call not yet folded into e->edges; step 3's validity test
 // needs edges of brand-new nodes only, which it derives locally.
-TrgStatus expand_bfs(TrgEngine *e, int ref_id) {
+// pre / pre_qi: GPU results of the root already fetched (entry pre_qi of chunk *pre, used by
+// updateGraph, which fetches all its roots in bulk); the root then needs no round trip of its own.
+TrgStatus expand_bfs(TrgEngine *e, int ref_id, Chunk *pre = nullptr, int pre_qi = 0) {
   TrgStatus st = ensure_chunks(e);
   if (st != TRG_OK) return st;
   const int S = e->prm.sample_num;
@@ -1190,7 +1207,7 @@ TrgStatus expand_bfs(TrgEngine *e, int ref_id) {
   e->queue.clear();
   e->queue.push_back(ref_id);
   size_t head = 0;        // next queue position to replay
-  size_t submitted = 0;   // queue positions [0, submitted) have been shipped to the GPU
+  size_t submitted = pre ? 1 : 0;  // queue positions [0, submitted) have been shipped to the GPU
   int next_buf = 0;       // chunk buffers are used round-robin, so completion order == queue order
   std::deque<int> inflight;  // chunk buffer indices in submission order
   std::vector<int> range_hits;
@@ -1225,7 +1242,8 @@ TrgStatus expand_bfs(TrgEngine *e, int ref_id) {
       st = ship(std::min<size_t>(avail, TrgEngine::CHUNK_MAX));
       if (st != TRG_OK) return st;
     }
-    if (!cur || (int)head >= cur->first + cur->count) {
+    const bool use_pre = pre && head == 0;
+    if (!use_pre && (!cur || (int)head >= cur->first + cur->count)) {
       cur = nullptr;
       if (inflight.empty()) return e->fail(TRG_ERR_DEVICE, "replay starved (internal error)");
       cur = &e->chunks[inflight.front()];
@@ -1233,19 +1251,19 @@ TrgStatus expand_bfs(TrgEngine *e, int ref_id) {
       st = wait_chunk(e, *cur);
       if (st != TRG_OK) return st;
     }
-
-    const int qi = (int)head - cur->first;
+    Chunk *const src = use_pre ? pre : cur;
+    const int qi = use_pre ? pre_qi : (int)head - cur->first;
     const int node = e->queue[head];
     head++;
     e->stats.expanded_nodes++;
-    const int n_acc = cur->n_acc.h[qi];
-    e->stats.trials += cur->n_draws.h[qi];
+    const int n_acc = src->n_acc.h[qi];
+    e->stats.trials += src->n_draws.h[qi];
     e->stats.samples += n_acc;
     e->stats.edge_evals_gpu += n_acc;
 
     for (int j = 0; j < n_acc; ++j) {
       const int slot = qi * S + j;
-      const float sx = cur->sx.h[slot], sy = cur->sy.h[slot];
+      const float sx = src->sx.h[slot], sy = src->sy.h[slot];
       // 1. nearest existing node (trg.cpp:408-417)
       const int ex = nearest_node(e, sx, sy);
       if (e->nstate[ex] == TRG_NODE_INVALID) continue;
@@ -1255,13 +1273,13 @@ TrgStatus expand_bfs(TrgEngine *e, int ref_id) {
       }
       // 2. new node (trg.cpp:420-426); its parent edge was evaluated speculatively on the GPU
       const int new_state = (ref_id == 0) ? TRG_NODE_VALID : TRG_NODE_FRONTIER;
-      const float sz = cur->sz.h[slot];
+      const float sz = src->sz.h[slot];
       const int nn = add_node_host(e, sx, sy, sz, new_state);
-      const float dist = cur->dist.h[slot];
-      const int stt = resolve_status(e, cur->status.h[slot], e->nz[node], sz, dist);
+      const float dist = src->dist.h[slot];
+      const int stt = resolve_status(e, src->status.h[slot], e->nz[node], sz, dist);
       const bool parent_ok = (stt == EDGE_OK);
       e->calls.push_back(
-          CallRec{node, nn, stt, parent_ok ? cur->weight.h[slot] : 0.0f, dist});
+          CallRec{node, nn, stt, parent_ok ? src->weight.h[slot] : 0.0f, dist});
       e->stats.edge_calls++;
       bool has_edge = parent_ok;
 
@@ -1533,13 +1551,18 @@ void trg_engine_destroy(TrgEngine *e) {
     (void)hipDeviceSynchronize();
     free_map(e->gmap);
     free_map(e->lmap);
-    for (Chunk &c : e->chunks) {
+    Chunk *all_chunks[TrgEngine::NCHUNK + 1];
+    for (int i = 0; i < TrgEngine::NCHUNK; ++i) all_chunks[i] = &e->chunks[i];
+    all_chunks[TrgEngine::NCHUNK] = &e->root_chunk;
+    for (Chunk *cp : all_chunks) {
+      Chunk &c = *cp;
       if (c.done) (void)hipEventDestroy(c.done);
       if (c.t0) (void)hipEventDestroy(c.t0);
       if (c.t1) (void)hipEventDestroy(c.t1);
       if (c.t2) (void)hipEventDestroy(c.t2);
       free_pinned(c.in_blob);
       free_pinned(c.out_blob);
+      free_pinned(c.mt);
       if (c.d_mid) (void)hipFree(c.d_mid);
     }
     for (EdgeBatch &b : e->ebatches) {
@@ -1835,14 +1858,27 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   }
   // isFrontier looked at the node set as it stood; expansions below mutate it, and the reference
   // evaluates isFrontier lazily inside the same loop BEFORE any expansion, so this order is exact.
-  for (int id : expand_queue) {
-    const size_t from = e->calls.size();
-    st = expand_bfs(e, id);
+  // The GPU results of a root (its samples and their speculative parent edges) depend on the map
+  // and on (seed, epoch, id) only, so they are fetched for all roots in bulk; the expansions
+  // themselves are replayed one root after the other, as the reference runs them.  wireEdge's
+  // dedupe does not influence any node decision, so the logged calls are evaluated and applied once
+  // at the end, in program order (first successful call per pair wins).
+  st = ensure_chunks(e);
+  if (st != TRG_OK) return st;
+  for (size_t g0 = 0; g0 < expand_queue.size(); g0 += TrgEngine::CHUNK_MAX) {
+    const int cnt = (int)std::min<size_t>(TrgEngine::CHUNK_MAX, expand_queue.size() - g0);
+    st = submit_nodes(e, e->root_chunk, expand_queue.data() + g0, cnt);
     if (st != TRG_OK) return st;
-    st = flush_pending(e, true);
+    st = wait_chunk(e, e->root_chunk);
     if (st != TRG_OK) return st;
-    apply_calls(e, from);  // the next expandGraph call's dedupe must see these edges
+    for (int i = 0; i < cnt; ++i) {
+      st = expand_bfs(e, expand_queue[g0 + i], &e->root_chunk, i);
+      if (st != TRG_OK) return st;
+    }
   }
+  st = flush_pending(e, true);
+  if (st != TRG_OK) return st;
+  apply_calls(e, 0);
   if (e->keep_preclean) snapshot_csr(e, e->csr_pre);
   clean_graph(e);
   snapshot_csr(e, e->csr_global);
