@@ -3,7 +3,8 @@
 The reference builds one graph from one root with one FIFO (trg.cpp:372-454); that BFS has a global
 order and does not shard without changing results.  What shards naturally
 is space: every rank owns one terrain tile and builds the complete graph of that tile (own map
-index, own root at the tile centre).  No data-path collective is needed; ranks only meet at the
+index, own root at the tile centre).  The tile-boundary edges are then stitched with two
+all-gather-v exchanges (tiled.py); besides those, ranks only meet at the
 barrier and in the throughput reduction.
 """
 from __future__ import annotations
