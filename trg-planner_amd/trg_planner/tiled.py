@@ -86,37 +86,45 @@ def allgatherv(arr, dist=None, device=None):
 
 def cross_pairs(my_tile, records_per_tile, expand_dist):
     """Pairs (index into my boundary list, other tile, index into its boundary list) with my tile
-    as the LOWER tile and fp32 planar distance < expand_dist.  records: float32 (k, 3) xyz.
+    as the LOWER tile and fp32 planar distance < expand_dist, as three int arrays ordered by
+    (other tile, my index, its index).  records: float32 (k, 3) xyz.
     A kd-tree prefilter (fp64, slightly enlarged radius) finds the candidates, the decision is the
     reference's fp32 expression (existing - sample).norm() < d, trg.cpp:414."""
     from scipy.spatial import cKDTree
     mine = records_per_tile[my_tile]
-    out = []
     d = np.float32(expand_dist)
-    if mine.shape[0] == 0:
-        return out
-    lo, hi = mine[:, :2].min(0) - 1.01 * d, mine[:, :2].max(0) + 1.01 * d
-    for u in range(my_tile + 1, len(records_per_tile)):
-        other = records_per_tile[u]
-        if other.shape[0] == 0:
-            continue
-        o_lo, o_hi = other[:, :2].min(0), other[:, :2].max(0)
-        if (o_lo > hi).any() or (o_hi < lo).any():
-            continue  # bounding boxes farther apart than expand_dist: no pair possible
-        tree = cKDTree(other[:, :2].astype(np.float64))
-        hits = tree.query_ball_point(mine[:, :2].astype(np.float64), r=float(expand_dist) * 1.001 + 1e-6)
-        ia = np.repeat(np.arange(mine.shape[0]), [len(h) for h in hits])
-        if ia.size == 0:
-            continue
-        ib = np.concatenate([np.asarray(h, np.int64) for h in hits if len(h)])
-        dx = mine[ia, 0] - other[ib, 0]
-        dy = mine[ia, 1] - other[ib, 1]
-        dist = np.sqrt(dx * dx + dy * dy, dtype=np.float32)  # fp32, no FMA
-        keep = dist < d
-        order = np.lexsort((ib[keep], ia[keep]))
-        for a, b in zip(ia[keep][order].tolist(), ib[keep][order].tolist()):
-            out.append((a, u, b))
-    return out
+    out_a, out_u, out_b = [], [], []
+    if mine.shape[0]:
+        lo, hi = mine[:, :2].min(0) - 1.01 * d, mine[:, :2].max(0) + 1.01 * d
+        my_tree = None
+        for u in range(my_tile + 1, len(records_per_tile)):
+            other = records_per_tile[u]
+            if other.shape[0] == 0:
+                continue
+            o_lo, o_hi = other[:, :2].min(0), other[:, :2].max(0)
+            if (o_lo > hi).any() or (o_hi < lo).any():
+                continue  # bounding boxes farther apart than expand_dist: no pair possible
+            if my_tree is None:
+                my_tree = cKDTree(mine[:, :2].astype(np.float64))
+            pairs = my_tree.sparse_distance_matrix(cKDTree(other[:, :2].astype(np.float64)),
+                                                   float(expand_dist) * 1.001 + 1e-6,
+                                                   output_type="coo_matrix")
+            ia, ib = pairs.row.astype(np.int64), pairs.col.astype(np.int64)
+            if ia.size == 0:
+                continue
+            dx = mine[ia, 0] - other[ib, 0]
+            dy = mine[ia, 1] - other[ib, 1]
+            dist = np.sqrt(dx * dx + dy * dy, dtype=np.float32)  # fp32, no FMA
+            keep = dist < d
+            ia, ib = ia[keep], ib[keep]
+            order = np.lexsort((ib, ia))
+            out_a.append(ia[order])
+            out_u.append(np.full(order.size, u, np.int64))
+            out_b.append(ib[order])
+    if not out_a:
+        z = np.zeros(0, np.int64)
+        return z, z, z
+    return np.concatenate(out_a), np.concatenate(out_u), np.concatenate(out_b)
 
 
 def assemble_global(tile_graphs, stitched):
@@ -155,15 +163,20 @@ def assemble_global(tile_graphs, stitched):
 def stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk):
     """Step 3 for one tile given every tile's boundary records: the cross edges this tile owns
     (it is the lower tile of the pair).  Returns (ids[k,4] int32, w[k], dist[k])."""
-    pairs = cross_pairs(my_tile, all_xyz, expand_dist)
-    if not pairs:
+    ia, iu, ib = cross_pairs(my_tile, all_xyz, expand_dist)
+    if ia.size == 0:
         return np.zeros((0, 4), np.int32), np.zeros(0, np.float32), np.zeros(0, np.float32)
-    p1 = np.stack([all_xyz[my_tile][a] for a, _, _ in pairs])
-    p2 = np.stack([all_xyz[u][b] for _, u, b in pairs])
+    p1 = all_xyz[my_tile][ia]
+    p2 = np.empty_like(p1)
+    id_b = np.empty(ia.size, np.int32)
+    for u in np.unique(iu):
+        sel = iu == u
+        p2[sel] = all_xyz[u][ib[sel]]
+        id_b[sel] = all_idx[u][ib[sel]]
     st, _, w, d = edge_risk(p1, p2)
     ok = st == 0
-    ids = np.array([[my_tile, all_idx[my_tile][a], u, all_idx[u][b]] for a, u, b in pairs],
-                   np.int32)[ok]
+    ids = np.stack([np.full(ia.size, my_tile, np.int32), all_idx[my_tile][ia].astype(np.int32),
+                    iu.astype(np.int32), id_b], 1)[ok]
     return ids, w[ok].astype(np.float32), d[ok].astype(np.float32)
 
 
