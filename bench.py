@@ -165,6 +165,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    if os.environ.get("TRG_BENCH_DEBUG"):
+        st_dbg = eng.stats()
+        sys.stderr.write(f"[bench rank {rank}] used_device_bfs={st_dbg['used_device_bfs']} "
+                         f"fallbacks={st_dbg['bfs_fallbacks']} max_spin={st_dbg['bfs_max_spin']} "
+                         f"levels={st_dbg['bfs_levels']} reason={eng.fallback_reason!r}\n")
     if world > 1:
         items, dt = tiling.reduce_throughput(items, dt, dist, coll_dev)
 
@@ -230,6 +235,7 @@ def main():
                 "ms_deferred": st["ms_deferred"], "ms_set_map_total": st["ms_set_map_total"],
                 "map_nn_resolved": st["map_nn_resolved"], "map_nn_unresolved": st["map_nn_unresolved"],
                 "ms_stitch_rank0": stitch_info.get("ms_stitch_last", 0.0),
+                "fallback_reason": eng.fallback_reason,
             },
         }
         if not args.no_cpu_baseline and world == 1:
