@@ -134,7 +134,8 @@ enum : int {
 };
 enum : int {
   BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
-  BFS_ERR_HASH = 16, BFS_ERR_LEVEL_TOO_BIG = 32, BFS_ERR_CLEAN = 64
+  BFS_ERR_HASH = 16, BFS_ERR_LEVEL_TOO_BIG = 32, BFS_ERR_CLEAN = 64,
+  BFS_ERR_STALL = 128  // k_bfs_resolve's bounded wait ran out: the level is replayed on the host
 };
 enum : int { CALL_NONE = -2, CALL_PENDING = -1 };
 
