@@ -135,3 +135,40 @@ def test_json_round_trip(oa, mountain_gentle, tmp_path):
         p1, i1 = e2.plan(s, g)
         assert p0.shape == p1.shape and p0.shape[0] > 1
         assert abs(i0.path_length - i1.path_length) < 1e-3
+
+
+@pytest.mark.parametrize("replay", ["device", "host"])
+@pytest.mark.parametrize("spacing", [0.04, 0.25])
+def test_dense_and_sparse_maps(oa, synth, replay, spacing):
+    """Map densities far from the benchmark's 0.1 m lattice: at 0.04 m a disc holds ~180 points and
+    an edge's box far more than the LDS tiles take (global-memory fallbacks of the disc query, the
+    median selection and the edge gather); at 0.25 m discs hold a handful of points and many edges
+    have fewer than three ellipse points."""
+    n = int(12.0 / spacing)
+    cloud = synth.mountain_cloud(n, n, seed=8, spacing=spacing, jitter=0.2 * spacing, amplitude=2.0,
+                                 wavelength=15.0)
+    prm = dict(oa.MOUNTAIN, sample_num=9)
+    start = [6.0, 6.0, 0.0]
+    e = _engine(oa, sample_num=9)
+    e.set_option("replay", replay)
+    e.set_option("keep_preclean", 1)
+    e.set_global_map(cloud)
+    o = oa.Oracle(**prm)
+    o.set_sampler(7, 0, 16)
+    o.set_global_map(cloud)
+    ok_o = bool(o.init_graph(start))
+    try:
+        e.init_graph(start)
+        ok_e = True
+    except Exception:
+        ok_e = False
+    assert ok_e == ok_o
+    if ok_e:
+        go = o.graph(1)
+        assert_graph_equal(e.graph("preclean"), go, 1e-5, allow_weight_outliers=max(2, go.E // 500))
+        assert_graph_equal(e.graph("global"), o.graph(0), 1e-5, allow_weight_outliers=max(2, go.E // 500))
+        rng = np.random.default_rng(3)
+        q = rng.uniform(1, 11, (400, 2)).astype(np.float32)
+        fe, ce, ne = e.is_collision(q)
+        fo, co, no = o.is_collision(q)
+        assert np.array_equal(fe, fo) and np.array_equal(ce, co) and np.array_equal(ne, no)
