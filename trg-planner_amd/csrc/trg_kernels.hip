@@ -1753,7 +1753,7 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
   __shared__ int r_col[2][SW];
   __shared__ unsigned long long r_hits[SW];
   __shared__ int r_ties[SW];
-  __shared__ int s_row[SBOX], row_off[SBOX + 1];
+  __shared__ int s_row[SBOX], row_off[SBOX + 1], row_len[SBOX];
   // count_dev: the frontier size lives on the device (launch issued before the host knew it; the
   // grid is an upper bound), node_base: first node of a follow-up launch
   const int node = (int)blockIdx.x + node_base;
@@ -1788,27 +1788,32 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
       L.cs[row][col] = m.cell_start[(box.cy0 + row) * m.W + box.cx0 + col];
     }
     __syncthreads();
-    if (tid == 0) {
-      // Every trial disc lies within R = d + r of the node: of each cell row only the columns that
-      // such a disc can reach are staged (the corners of the box are never read).  The bounds are
-      // conservative by millimetres; which points a disc accepts is decided by the exact test.
+    // Every trial disc lies within R = d + r of the node: of each cell row only the columns that
+    // such a disc can reach are staged (the corners of the box are never read).  The bounds are
+    // conservative by millimetres; which points a disc accepts is decided by the exact test.
+    if (tid < nrows) {
+      const int row = tid;
       const float R = (p.expand_dist + p.robot_size) * 1.002f + 2e-3f;
       const float g = 1.0f / m.inv_g;
+      const float yc = m.y0 + ((float)(box.cy0 + row) + 0.5f) * g;
+      const float dy = fmaxf(fabsf(yc - py) - 0.5f * g - 2e-3f, 0.0f);
+      int c_lo = 0, c_hi = -1;  // empty row
+      if (dy < R) {
+        const float hx = sqrtf(R * R - dy * dy) + 2e-3f;
+        c_lo = max(cell_coord(px - hx, m.x0, m.inv_g, m.W) - box.cx0, 0);
+        c_hi = min(cell_coord(px + hx, m.x0, m.inv_g, m.W) - box.cx0, ncols - 1);
+      }
+      const int a = c_hi >= c_lo ? L.cs[row][c_lo] : L.cs[row][0];
+      const int bnd = c_hi >= c_lo ? L.cs[row][c_hi + 1] : L.cs[row][0];
+      s_row[row] = a;
+      row_len[row] = bnd - a;
+    }
+    __syncthreads();
+    if (tid == 0) {
       int acc = 0;
       for (int row = 0; row < nrows; ++row) {
-        const float yc = m.y0 + ((float)(box.cy0 + row) + 0.5f) * g;
-        const float dy = fmaxf(fabsf(yc - py) - 0.5f * g - 2e-3f, 0.0f);
-        int c_lo = 0, c_hi = -1;  // empty row
-        if (dy < R) {
-          const float hx = sqrtf(R * R - dy * dy) + 2e-3f;
-          c_lo = max(cell_coord(px - hx, m.x0, m.inv_g, m.W) - box.cx0, 0);
-          c_hi = min(cell_coord(px + hx, m.x0, m.inv_g, m.W) - box.cx0, ncols - 1);
-        }
-        const int a = c_hi >= c_lo ? L.cs[row][c_lo] : L.cs[row][0];
-        const int b = c_hi >= c_lo ? L.cs[row][c_hi + 1] : L.cs[row][0];
-        s_row[row] = a;
         row_off[row] = acc;
-        acc += b - a;
+        acc += row_len[row];
       }
       row_off[nrows] = acc;
       L.total = acc;
