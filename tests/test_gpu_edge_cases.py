@@ -172,3 +172,41 @@ def test_dense_and_sparse_maps(oa, synth, replay, spacing):
         fe, ce, ne = e.is_collision(q)
         fo, co, no = o.is_collision(q)
         assert np.array_equal(fe, fo) and np.array_equal(ce, co) and np.array_equal(ne, no)
+
+
+def test_engine_reuse_across_maps_of_different_size(oa, synth):
+    """One engine, three maps in a row (small -> large -> small, different extents and sample
+    counts are not possible on one engine, so only the maps change): every device buffer is sized on
+    demand and reused; each build must equal a fresh engine's build of the same map (compared through
+    the creation ids, because cleanGraph's renumbering depends on the container's bucket history)."""
+    import trg_planner
+    maps = [synth.mountain_cloud(200, 200, seed=1), synth.mountain_cloud(500, 450, seed=2, origin=(-7.0, 3.0)),
+            synth.mountain_cloud(150, 260, seed=3, origin=(40.0, -12.0))]
+    starts = [[10.0, 10.0, 0.0], [18.0, 25.0, 0.0], [47.5, 1.0, 0.0]]
+    prm = dict(oa.MOUNTAIN, sample_num=12)
+    shared = trg_planner.Engine(**prm)
+    shared.set_sampler(9, 16)
+    for cloud, start in zip(maps, starts):
+        shared.set_global_map(cloud)
+        shared.init_graph(start)
+        assert shared.stats()["used_device_bfs"] == 1, shared.fallback_reason
+        fresh = trg_planner.Engine(**prm)
+        fresh.set_sampler(9, 16)
+        fresh.set_global_map(cloud)
+        fresh.init_graph(start)
+        a, b = shared.graph("global"), fresh.graph("global")
+        assert a.V == b.V and a.E == b.E and a.V > 100
+        oa_, ob_ = np.argsort(a.cid), np.argsort(b.cid)
+        assert np.array_equal(a.cid[oa_], b.cid[ob_])
+        assert np.array_equal(a.xyz[oa_].view(np.uint32), b.xyz[ob_].view(np.uint32))
+        assert np.array_equal(np.diff(a.rowptr)[oa_], np.diff(b.rowptr)[ob_])
+        # same edges (as creation-id pairs) with the same weights
+        def edges(g):
+            src = np.repeat(np.arange(g.V), np.diff(g.rowptr))
+            key = g.cid[src].astype(np.int64) * (1 << 32) + g.cid[g.col]
+            o = np.argsort(key)
+            return key[o], g.w[o], g.dist[o]
+        ka, wa, da = edges(a)
+        kb, wb, db = edges(b)
+        assert np.array_equal(ka, kb) and np.array_equal(wa.view(np.uint32), wb.view(np.uint32))
+        assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
