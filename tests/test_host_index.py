@@ -23,3 +23,20 @@ def test_map_order_replica_matches_libstdcxx(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "map_order_check.cpp"), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_host_checks_under_sanitizers(oa, tmp_path):
+    """The host-side structures of the engine that can run without a GPU (NodeKd / NodeGrid /
+    tie-break, container-order replica) under AddressSanitizer + UBSan."""
+    flags = ["-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+             "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"]
+    okd_o = tmp_path / "okd_asan.o"
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-c", os.path.join(ROOT, "oracle", "okd.c"), "-o", str(okd_o)])
+    for src, extra in (("host_index_check.cpp", [str(okd_o)]), ("map_order_check.cpp", [])):
+        exe = tmp_path / (src + ".asan")
+        subprocess.check_call(["g++"] + flags + ["-I", os.path.join(ROOT, "oracle"),
+                                                 os.path.join(ROOT, "tests", "cpp", src)] + extra +
+                              ["-o", str(exe)])
+        out = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
