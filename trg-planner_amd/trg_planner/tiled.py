@@ -187,15 +187,16 @@ def stitch(my_tile, graph, core, cols, rows, expand_dist, edge_risk, dist=None, 
     and the number of boundary records exchanged."""
     bidx = boundary_nodes(graph.xyz, core, cols, rows, my_tile, expand_dist)
     # exchange 1: boundary records (local id, x, y, z), 16 bytes each, one all-gather-v
-    rec = np.empty((bidx.shape[0], 4), np.float32)
-    rec[:, 0] = bidx.view(np.float32)
-    rec[:, 1:] = graph.xyz[bidx]
+    # (carried as int32 words: the payload is only ever copied, never computed on)
+    rec = np.empty((bidx.shape[0], 4), np.int32)
+    rec[:, 0] = bidx
+    rec[:, 1:] = np.ascontiguousarray(graph.xyz[bidx], dtype=np.float32).view(np.int32)
     all_rec = allgatherv(rec, dist, device)
     if len(all_rec) == 1:  # single process: nothing to stitch against
         z = np.zeros(0, np.float32)
         return (np.zeros((0, 4), np.int32), z, z), 0
-    all_idx = [np.ascontiguousarray(r[:, 0]).view(np.int32) for r in all_rec]
-    all_xyz = [np.ascontiguousarray(r[:, 1:]) for r in all_rec]
+    all_idx = [np.ascontiguousarray(r[:, 0]) for r in all_rec]
+    all_xyz = [np.ascontiguousarray(r[:, 1:]).view(np.float32) for r in all_rec]
     ids, w, d = stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk)
     # exchange 2: the cross edges this tile owns (tile_a, id_a, tile_b, id_b, weight, dist), 24 bytes
     out = np.empty((ids.shape[0], 6), np.int32)
