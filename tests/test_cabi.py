@@ -20,11 +20,12 @@ def test_build_and_exports():
         assert hasattr(lib, sym), sym
 
 
-def test_code_object_is_gfx950_only():
+def test_code_object_is_gfx950_only(tmp_path):
     import subprocess
     import trg_planner
+    # llvm-objdump --offloading drops the extracted code objects into its working directory
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", trg_planner.LIB_PATH],
-                         capture_output=True, text=True).stdout
+                         capture_output=True, text=True, cwd=str(tmp_path)).stdout
     archs = set(re.findall(r"gfx[0-9a-f]+", out))
     assert archs == {"gfx950"}, archs
 

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/trg_engine.h"
+#include "graph_json.h"
 #include "host_index.h"
 #include "map_order_sim.h"
 #include "trg_kernels.h"
@@ -1940,78 +1941,21 @@ TrgStatus trg_engine_save_json(TrgEngine *e, const char *path) {
   std::ofstream f(p);
   if (!f) return e->fail(TRG_ERR_IO, "cannot open " + p);
   ensure_pool(e);
-  char buf[256];
-  f << "{\n    \"edges\": [";
   // nodes/edges are listed in the node map's iteration order, like the reference
-  bool first = true;
   std::vector<int> map_order;
   node_map_order(e, map_order);
+  GraphJson g;
+  g.nodes.reserve(map_order.size());
   for (int id : map_order) {
-    for (int ed = e->edges.head[id]; ed >= 0; ed = e->edges.next[ed]) {
-      snprintf(buf, sizeof(buf),
-               "%s\n        {\n            \"dist\": %.9g,\n            \"source\": %d,\n"
-               "            \"target\": %d,\n            \"weight\": %.9g\n        }",
-               first ? "" : ",", (double)e->edges.dist[ed], id, e->edges.dst[ed],
-               (double)e->edges.w[ed]);
-      f << buf;
-      first = false;
-    }
+    g.nodes.push_back({id, {e->nx[id], e->ny[id], e->nz[id]}, e->nstate[id]});
+    for (int ed = e->edges.head[id]; ed >= 0; ed = e->edges.next[ed])
+      g.edges.push_back({id, e->edges.dst[ed], e->edges.w[ed], e->edges.dist[ed]});
   }
-  f << (first ? "]" : "\n    ]") << ",\n    \"nodes\": [";
-  first = true;
-  for (int id : map_order) {
-    snprintf(buf, sizeof(buf),
-             "%s\n        {\n            \"id\": %d,\n            \"pos\": [\n                %.9g,\n"
-             "                %.9g,\n                %.9g\n            ],\n            \"state\": %d\n"
-             "        }",
-             first ? "" : ",", id, (double)e->nx[id], (double)e->ny[id], (double)e->nz[id],
-             e->nstate[id]);
-    f << buf;
-    first = false;
-  }
-  f << (first ? "]" : "\n    ]") << "\n}";
+  write_graph_json(f, g);
   f.close();
   if (!f) return e->fail(TRG_ERR_IO, "write failed: " + p);
   return TRG_OK;
 }
-
-namespace {
-// minimal JSON reader for the graph schema: arrays of flat objects with numeric members
-struct JsonCursor {
-  const std::string &s;
-  size_t i = 0;
-  explicit JsonCursor(const std::string &str) : s(str) {}
-  void ws() {
-    while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i;
-  }
-  bool eat(char c) {
-    ws();
-    if (i < s.size() && s[i] == c) {
-      ++i;
-      return true;
-    }
-    return false;
-  }
-  bool str(std::string &out) {
-    ws();
-    if (i >= s.size() || s[i] != '"') return false;
-    size_t j = s.find('"', i + 1);
-    if (j == std::string::npos) return false;
-    out = s.substr(i + 1, j - i - 1);
-    i = j + 1;
-    return true;
-  }
-  bool num(double &out) {
-    ws();
-    const char *b = s.c_str() + i;
-    char *end = nullptr;
-    out = strtod(b, &end);
-    if (end == b) return false;
-    i += (size_t)(end - b);
-    return true;
-  }
-};
-}  // namespace
 
 TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
   REQUIRE_DEVICE(e);
@@ -2021,66 +1965,14 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
   std::stringstream ss;
   ss << f.rdbuf();
   const std::string txt = ss.str();
-  struct N {
-    int id;
-    float p[3];
-    int state;
-  };
-  struct Ed {
-    int s, t;
-    float w, d;
-  };
-  std::vector<N> nodes;
-  std::vector<Ed> eds;
-  JsonCursor c(txt);
-  if (!c.eat('{')) return e->fail(TRG_ERR_IO, "Failed to load graph: not a JSON object");
-  while (true) {
-    std::string key;
-    if (!c.str(key)) break;
-    if (!c.eat(':') || !c.eat('[')) return e->fail(TRG_ERR_IO, "Failed to load graph: bad array");
-    while (c.eat('{')) {
-      N n{0, {0, 0, 0}, 0};
-      Ed ed{0, 0, 0, 0};
-      while (true) {
-        std::string k;
-        if (!c.str(k)) break;
-        if (!c.eat(':')) return e->fail(TRG_ERR_IO, "Failed to load graph: bad member");
-        double v = 0;
-        if (k == "pos") {
-          if (!c.eat('[')) return e->fail(TRG_ERR_IO, "Failed to load graph: bad pos");
-          for (int q = 0; q < 3; ++q) {
-            if (!c.num(v)) return e->fail(TRG_ERR_IO, "Failed to load graph: bad pos");
-            n.p[q] = (float)v;
-            c.eat(',');
-          }
-          c.eat(']');
-        } else {
-          if (!c.num(v)) return e->fail(TRG_ERR_IO, "Failed to load graph: bad number");
-          if (k == "id") n.id = (int)v;
-          else if (k == "state") n.state = (int)v;
-          else if (k == "source") ed.s = (int)v;
-          else if (k == "target") ed.t = (int)v;
-          else if (k == "weight") ed.w = (float)v;
-          else if (k == "dist") ed.d = (float)v;
-        }
-        if (!c.eat(',')) break;
-      }
-      if (!c.eat('}')) return e->fail(TRG_ERR_IO, "Failed to load graph: unterminated object");
-      if (key == "nodes") nodes.push_back(n);
-      else if (key == "edges") eds.push_back(ed);
-      if (!c.eat(',')) break;
-    }
-    if (!c.eat(']')) return e->fail(TRG_ERR_IO, "Failed to load graph: unterminated array");
-    if (!c.eat(',')) break;
-  }
-  // loadPrebuiltGraph (trg.cpp:78-120): ids must be dense for the slot == id layout
-  ensure_real_map(e);
-  int max_id = -1;
-  for (auto &n : nodes) max_id = std::max(max_id, n.id);
-  if (max_id + 1 != (int)nodes.size())
-    return e->fail(TRG_ERR_IO, "Failed to load graph: node ids are not dense 0..V-1");
-  reset_graph_global(e);
+  GraphJson gj;
+  std::string perr;
+  if (!parse_graph_json(txt, gj, perr) || !validate_graph_json(gj, perr)) return e->fail(TRG_ERR_IO, perr);
+  const std::vector<GraphJson::N> &nodes = gj.nodes;
+  const std::vector<GraphJson::Ed> &eds = gj.edges;
   const size_t V = nodes.size();
+  ensure_real_map(e);
+  reset_graph_global(e);
   e->nx.assign(V, 0);
   e->ny.assign(V, 0);
   e->nz.assign(V, 0);
@@ -2097,10 +1989,7 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
     e->kd_insert_order.push_back(n.id);  // kd_insert2 in file order (trg.cpp:103)
   }
   e->node_id = (int)V;
-  for (auto &ed : eds) {
-    if (ed.s < 0 || ed.s >= (int)V) continue;
-    e->edges.push(ed.s, ed.t, ed.w, ed.d);
-  }
+  for (auto &ed : eds) e->edges.push(ed.s, ed.t, ed.w, ed.d);
   e->kd_valid = false;
   grid_rebuild(e);
   e->host_grid_valid = true;

@@ -25,6 +25,9 @@ class OperationResponse:  # interface/operation.h:23-26
     def __init__(self, success=False, message=""):
         self.success, self.message = success, message
 
+    def __bool__(self):
+        return bool(self.success)
+
 
 class TRGPlanner:
     GRAPH_STATES = ("INIT", "UPDATE", "EXPAND", "LOAD", "SAVE", "RESET")
@@ -237,6 +240,8 @@ class TRGPlanner:
 
     def shutdown(self):
         self.is_running = False
+        if self._fifo_path:
+            self.stopCommandInterface()
         for t in self._threads:
             t.join(timeout=5)
         self._threads = []
@@ -297,28 +302,63 @@ class TRGPlanner:
         return r
 
     def setupCommandInterface(self, pipe_path="/tmp/trg_planner_fifo"):
-        """Named-pipe listener: each request is three lines (type, command, filepath)."""
+        """Named-pipe listener (interface.cpp:19-29, 60-131): the pipe is opened non-blocking, switched
+        back to blocking, and ONE request -- three newline-terminated lines type / command / filepath
+        -- is read per open; an empty read (no writer) is retried after 100 ms."""
+        import fcntl
         if os.path.exists(pipe_path):
             os.unlink(pipe_path)
         os.mkfifo(pipe_path, 0o666)
         self._fifo_path = pipe_path
+        self._fifo_running = True
 
         def listen():
-            while self.is_running:
+            while self._fifo_running:
                 try:
-                    with open(pipe_path, "r") as f:
-                        lines = [ln.rstrip("\n") for ln in f.readlines()]
+                    fd = os.open(pipe_path, os.O_RDONLY | os.O_NONBLOCK)
                 except OSError:
-                    break
-                for i in range(0, len(lines) - 2, 3):
-                    self.processOperation(lines[i], lines[i + 1], lines[i + 2])
+                    time.sleep(1.0)
+                    continue
+                fcntl.fcntl(fd, fcntl.F_SETFL, fcntl.fcntl(fd, fcntl.F_GETFL) & ~os.O_NONBLOCK)
+                with os.fdopen(fd, "r") as f:
+                    req = [f.readline()[:1023].rstrip("\n") for _ in range(3)]
+                if req[0] and req[1]:
+                    self.processOperation(req[0], req[1], req[2])
+                time.sleep(0.1)
 
         t = threading.Thread(target=listen, daemon=True)
         t.start()
+        self._fifo_thread = t
         return True
+
+    def stopCommandInterface(self):
+        """TRGInterface::stopCommandListener + cleanup (interface.cpp:47-58, 31-33)."""
+        self._fifo_running = False
+        t = getattr(self, "_fifo_thread", None)
+        if t is not None:
+            t.join(timeout=3)
+        if self._fifo_path and os.path.exists(self._fifo_path):
+            os.unlink(self._fifo_path)
+        self._fifo_path = None
 
     @staticmethod
     def sendCommand(type, command, filepath="", pipe_path="/tmp/trg_planner_fifo"):
-        with open(pipe_path, "w") as f:
-            f.write(f"{type}\n{command}\n{filepath}\n")
-        return True
+        """TRGInterface::sendCommand (interface.cpp:133-165): three lines into the named pipe."""
+        import stat
+        r = OperationResponse()
+        try:
+            is_fifo = stat.S_ISFIFO(os.stat(pipe_path).st_mode)
+        except OSError:
+            is_fifo = False
+        if not is_fifo:
+            r.message = "Command pipe not found. Is TRG Planner running?"
+            return r
+        try:
+            with open(pipe_path, "w") as f:
+                f.write(f"{type}\n{command}\n{filepath}\n")
+        except OSError:
+            r.message = "Failed to open command pipe. Is TRG Planner running?"
+            return r
+        r.success = True
+        r.message = "Command sent: " + type + " " + command + (f" (file: {filepath})" if filepath else "")
+        return r
