@@ -19,7 +19,7 @@ COUNTER_NAMES = [
     "collision_queries", "collision_hits", "nn_map_queries", "ellipse_queries", "ellipse_hits",
     "wire_calls", "wire_evals", "wire_ok", "wire_gate", "wire_seg", "wire_empty", "wire_few",
     "wire_clamped", "expanded", "trials", "samples", "created", "invalid_created",
-    "nn_node_queries", "_pad",
+    "nn_node_queries", "sample_hits",
 ]
 
 

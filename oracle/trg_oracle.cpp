@@ -380,6 +380,7 @@ struct OCounters {
   uint64_t wire_gate = 0, wire_seg = 0, wire_empty = 0, wire_few = 0, wire_clamped = 0;
   uint64_t expanded = 0, trials = 0, samples = 0, created = 0, invalid_created = 0;
   uint64_t nn_node_queries = 0;
+  uint64_t sample_hits = 0;  // the part of collision_hits issued by expandGraph's sampling loop (trg.cpp:398)
 };
 
 inline float norm2(float dx, float dy) { return std::sqrt(dx * dx + dy * dy); }
@@ -755,7 +756,10 @@ class Oracle {
         cnt_.trials++;
         float sx = node->pos_[0] + expand_dist * cs;
         float sy = node->pos_[1] + expand_dist * sn;
-        if (isCollision(sx, sy, type, param_.collision_threshold) || !inCore(sx, sy)) {
+        const uint64_t hits_before = cnt_.collision_hits;
+        const bool sample_collides = isCollision(sx, sy, type, param_.collision_threshold);
+        cnt_.sample_hits += cnt_.collision_hits - hits_before;
+        if (sample_collides || !inCore(sx, sy)) {
           trial_sample++;
           continue;
         }
@@ -1395,7 +1399,7 @@ void trg_oracle_counters(void *h, uint64_t *out) {
                   c.ellipse_hits,      c.wire_calls,     c.wire_evals,     c.wire_ok,
                   c.wire_gate,         c.wire_seg,       c.wire_empty,     c.wire_few,
                   c.wire_clamped,      c.expanded,       c.trials,         c.samples,
-                  c.created,           c.invalid_created, c.nn_node_queries, 0};
+                  c.created,           c.invalid_created, c.nn_node_queries, c.sample_hits};
   memcpy(out, v, sizeof(v));
 }
 void trg_oracle_reset_counters(void *h) { ((Oracle *)h)->cnt_ = OCounters(); }

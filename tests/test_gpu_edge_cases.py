@@ -82,8 +82,8 @@ def test_tiny_and_degenerate_maps(oa, replay):
             ok_e = False
         assert ok_e == bool(ok_o)
         if ok_e:
-            assert_graph_equal(e.graph("preclean"), o.graph(1), 1e-5, allow_weight_outliers=2)
-            assert_graph_equal(e.graph("global"), o.graph(0), 1e-5, allow_weight_outliers=2)
+            assert_graph_equal(e.graph("preclean"), o.graph(1), 1e-5)
+            assert_graph_equal(e.graph("global"), o.graph(0), 1e-5)
 
 
 def test_zero_length_and_long_edges(oa, mountain_gentle):
@@ -165,8 +165,8 @@ def test_dense_and_sparse_maps(oa, synth, replay, spacing):
     assert ok_e == ok_o
     if ok_e:
         go = o.graph(1)
-        assert_graph_equal(e.graph("preclean"), go, 1e-5, allow_weight_outliers=max(2, go.E // 500))
-        assert_graph_equal(e.graph("global"), o.graph(0), 1e-5, allow_weight_outliers=max(2, go.E // 500))
+        assert_graph_equal(e.graph("preclean"), go, 1e-5)
+        assert_graph_equal(e.graph("global"), o.graph(0), 1e-5)
         rng = np.random.default_rng(3)
         q = rng.uniform(1, 11, (400, 2)).astype(np.float32)
         fe, ce, ne = e.is_collision(q)

@@ -90,5 +90,5 @@ def test_build_with_tied_elevation_lookups(oa, synth, replay):
     assert st["map_nn_resolved"] > 20 and st["map_nn_unresolved"] == 0, st
     go = o.graph(1)
     assert go.V > 200
-    assert_graph_equal(e.graph("preclean"), go, 1e-5, allow_weight_outliers=max(2, go.E // 500))
-    assert_graph_equal(e.graph("global"), o.graph(0), 1e-5, allow_weight_outliers=max(2, go.E // 500))
+    assert_graph_equal(e.graph("preclean"), go, 1e-5)
+    assert_graph_equal(e.graph("global"), o.graph(0), 1e-5)

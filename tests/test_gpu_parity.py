@@ -129,15 +129,16 @@ def test_edge_risk_parity(oa, request, cloud_name):
     ok = so == 0
     assert np.array_equal(ne[ok | (so == 4)], no[ok | (so == 4)])
     assert ok.sum() > 100
-    dw = np.abs(we[ok].astype(np.float64) - wo[ok])
-    # literal fp32 oracle: summation-order noise amplified by the eigen-gap; bar is 1e-5
-    assert (dw > WEIGHT_TOL).mean() < 2e-3, (int((dw > WEIGHT_TOL).sum()), float(dw.max()))
-    # same formula with fp64 moments in the oracle: must agree far tighter
+    # Two witnesses.  (i) The literal fp32 restatement of trg.cpp:332-338: every edge within 1e-5,
+    # clamp flips counted apart.  (ii) The same formula with fp64 accumulation: far tighter.
+    from conftest import weight_report
+    flips, others, mx = weight_report(we[ok], wo[ok], WEIGHT_TOL)
+    assert others == 0 and flips == 0, (flips, others, mx)
     o.set_cov_f64(True)
     so2, _, wo2, _ = o.edge_risk(p1, p2)
-    dw2 = np.abs(we[ok].astype(np.float64) - wo2[ok])
     assert np.array_equal(so2, so)
-    assert float(dw2.max()) <= 2e-6, float(dw2.max())
+    flips2, others2, mx2 = weight_report(we[ok], wo2[ok], 2e-6)
+    assert others2 == 0 and flips2 == 0, (flips2, others2, mx2)
 
 
 def _build_both(oa, prm, cloud, start, seed, replay=None):
@@ -177,9 +178,9 @@ def test_init_graph_parity(oa, request, case, replay):
         e.fallback_reason
     pre_e, pre_o = e.graph("preclean"), o.graph(1)
     assert pre_o.V > 200, pre_o.V
-    assert_graph_equal(pre_e, pre_o, WEIGHT_TOL, allow_weight_outliers=max(2, pre_o.E // 500))
+    assert_graph_equal(pre_e, pre_o, WEIGHT_TOL)
     ge, go = e.graph("global"), o.graph(0)
-    assert_graph_equal(ge, go, WEIGHT_TOL, allow_weight_outliers=max(2, go.E // 500))
+    assert_graph_equal(ge, go, WEIGHT_TOL)
     st = e.stats()
     c = o.counters()
     assert st["expanded_nodes"] == c["expanded"]
@@ -187,6 +188,9 @@ def test_init_graph_parity(oa, request, case, replay):
     assert st["samples"] == c["samples"]
     assert st["created_nodes"] == c["created"]
     assert st["invalid_nodes"] == c["invalid_created"]
+    # algorithmic bytes of the sampling kernel == 12 B x the map points inside the discs of the
+    # reference's own sampling loop (B_alg counted by the oracle's instrumentation)
+    assert st["bytes_sample_kernel"] == 12 * c["sample_hits"], (st["bytes_sample_kernel"], c["sample_hits"])
     assert st["nn_ties"] == 0 and st["map_nn_ties"] == 0
     # invariants of the reference
     assert (ge.state != -1).all() and (np.diff(ge.rowptr) >= 1).all()
@@ -252,7 +256,7 @@ def test_repeated_builds_are_identical(oa, mountain_small):
     for start in ([15.0, 15.0, 0.0], [9.0, 21.0, 0.0]):
         e.init_graph(start)
         assert o.init_graph(start)
-        assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)
+        assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
 
 
 def test_tie_levels_replayed_on_host_give_the_same_graph(oa, mountain_small):
@@ -273,8 +277,38 @@ def test_tie_levels_replayed_on_host_give_the_same_graph(oa, mountain_small):
     o.set_sampler(21, 0, 16)
     o.set_global_map(mountain_small)
     assert o.init_graph([15.0, 15.0, 0.0])
-    assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL, allow_weight_outliers=3)
-    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)
+    assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL)
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
+    c = o.counters()
+    assert st["trials"] == c["trials"] and st["samples"] == c["samples"]
+    assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
+
+
+def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
+    """k_bfs_resolve's inter-workgroup wait is bounded; when it runs out (BFS_ERR_STALL) the level is
+    left PARTIALLY decided -- outcomes 0 / 7 in c_outcome, commit and emit have run on them.  The
+    hook leaves the middle candidate of one mid-build level undecided (everything that waits for it
+    runs into the bound): the engine must take the level back (k_bfs_undo_commit), replay it on the
+    host and continue on the device, and the graph must still equal the oracle's."""
+    prm = dict(oa.MOUNTAIN, sample_num=10)
+    e = _engine(prm)
+    e.set_sampler(21, 16)
+    e.set_option("keep_preclean", 1)
+    e.set_global_map(mountain_small)
+    e.init_graph([15.0, 15.0, 0.0])
+    natural = e.stats()["bfs_host_levels"]  # this cloud has one real nearest-node tie (level 71)
+    e.set_option("debug_stall_level", 9)
+    e.set_global_map(mountain_small)
+    e.init_graph([15.0, 15.0, 0.0])
+    st = e.stats()
+    assert st["used_device_bfs"] == 1 and st["bfs_fallbacks"] == 0, (st, e.fallback_reason)
+    assert st["bfs_host_levels"] == natural + 1, (st["bfs_host_levels"], natural)
+    o = oa.Oracle(**prm)
+    o.set_sampler(21, 0, 16)
+    o.set_global_map(mountain_small)
+    assert o.init_graph([15.0, 15.0, 0.0])
+    assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL)
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
     c = o.counters()
     assert st["trials"] == c["trials"] and st["samples"] == c["samples"]
     assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
@@ -327,8 +361,8 @@ def test_uncertain_slope_gates_are_decided_by_host_libm(oa, mountain_small, repl
     o.set_global_map(mountain_small)
     assert o.init_graph([15.0, 15.0, 0.0])
     assert o.counters()["wire_gate"] > 0
-    assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL, allow_weight_outliers=3)
-    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)
+    assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL)
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
 
 
 def test_speculative_sampling_bound_and_top_up(oa, mountain_small):
@@ -344,7 +378,7 @@ def test_speculative_sampling_bound_and_top_up(oa, mountain_small):
     e2.set_global_map(mountain_small)
     e2.init_graph([15.0, 15.0, 0.0])
     assert e2.stats()["used_device_bfs"] == 1, e2.fallback_reason
-    assert_graph_equal(e2.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)
+    assert_graph_equal(e2.graph("global"), o.graph(0), WEIGHT_TOL)
     assert_graph_equal(e2.graph("global"), ref, 0.0)
     for k in ("trials", "samples", "created_nodes", "invalid_nodes"):
         assert e2.stats()[k] == e.stats()[k], k
@@ -366,4 +400,4 @@ def test_device_bfs_declining_falls_back_to_the_host_replay(oa, mountain_small):
     o.set_sampler(7, 0, 16)
     o.set_global_map(mountain_small)
     assert o.init_graph([15.0, 15.0, 0.0])
-    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL, allow_weight_outliers=3)
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)

@@ -32,7 +32,7 @@ def test_update_graph_parity(oa, mountain_gentle, replay):
     o.set_sampler(5, 0, 16)
     o.set_global_map(mountain_gentle)
     assert o.init_graph([15.0, 15.0, 0.0])
-    assert_graph_equal(e.graph("global"), o.graph(0), TOL, allow_weight_outliers=3)
+    assert_graph_equal(e.graph("global"), o.graph(0), TOL)
 
     poses = [(12.0, 12.0), (13.0, 12.5), (14.0, 13.0)]
     for k, pose in enumerate(poses):

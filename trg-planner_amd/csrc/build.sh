@@ -15,3 +15,12 @@ if [ ! -f "$HERE/_obj/trg_voxel.o" ] || [ "$HERE/trg_voxel.hip" -nt "$HERE/_obj/
 fi
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/_obj/trg_kernels.o" "$HERE/_obj/trg_engine.o" "$HERE/_obj/trg_voxel.o" -o "$HERE/libtrg_engine.so"
 echo "built $HERE/libtrg_engine.so"
+# pybind11 module trg_planner._trg_pybind: the reference's Python surface (TRG, Edge, NodeState, Node)
+# over include/trg_shim.hpp, i.e. over the C ABI of the library above
+PY="${PYTHON:-python3}"
+PYINC="$("$PY" -c "import sysconfig; print(sysconfig.get_paths()['include'])")"
+PBINC="$("$PY" -c "import pybind11; print(pybind11.get_include())")"
+EXT="$("$PY" -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")"
+g++ -O2 -std=c++17 -fPIC -shared -fvisibility=hidden -I"$PYINC" -I"$PBINC" "$HERE/trg_pybind.cpp" \
+  -L"$HERE" -ltrg_engine -Wl,-rpath,'$ORIGIN/../csrc' -o "$HERE/../trg_planner/_trg_pybind$EXT"
+echo "built $HERE/../trg_planner/_trg_pybind$EXT"

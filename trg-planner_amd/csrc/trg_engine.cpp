@@ -332,6 +332,7 @@ struct TrgEngine {
   int debug_tie_every = 0;       // test hook: treat every n-th BFS level as tie-affected
   int debug_spec_bound = 0;      // test hook: cap the speculative sampling launch at n nodes
   int debug_fallback_level = -1; // test hook: the device BFS declines at this level
+  int debug_stall_level = -1;    // test hook: k_bfs_resolve leaves one candidate of this level undecided
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
@@ -1782,6 +1783,10 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_spec_bound") {
     e->debug_spec_bound = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "debug_stall_level") {
+    e->debug_stall_level = atoi(v.c_str());
     return TRG_OK;
   }
   if (k == "debug_fallback_level") {

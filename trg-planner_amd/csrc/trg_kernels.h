@@ -200,7 +200,7 @@ void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int co
 // neighbour lists + resolve + call emission
 constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-resident (<= 512 groups)
 void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
-                        int V0, int ncand_bound, hipStream_t s);
+                        int V0, int ncand_bound, hipStream_t s, bool stall_test = false);
 void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
 void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, const int *list, int count,
                        DeviceCounters *ctr, hipStream_t s);

@@ -1884,15 +1884,16 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
     const bool collides = disc_collides(d, p.collision_threshold) || !in_core;
     int *colbuf = r_col[round & 1];  // double-buffered: one barrier per round
     if (lane == 0) colbuf[w] = collides ? 1 : 0;
-    hits += (unsigned long long)d.n;
     __syncthreads();
     // In-order acceptance (trg.cpp:386-402).  The round's reject flags are packed into one mask so
     // that the sequential loop runs on the scalar unit; the wave whose draw is accepted stores it.
     const unsigned long long colmask = ballot(lane < SW && colbuf[lane < SW ? lane : 0] != 0);
     int my_slot = -1;
+    int consumed = 0;  // draws of this round the sequential loop really made
     for (int i = 0; i < SW; ++i) {
       if (n_acc >= S || rejects > max_trial_sample) break;
       draws++;
+      consumed++;
       if ((colmask >> i) & 1ull) {
         rejects++;
       } else {
@@ -1900,6 +1901,9 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
         n_acc++;
       }
     }
+    // instrumentation counts the reference's queries only: a draw evaluated past the loop's
+    // stopping point was never issued by expandGraph (trg.cpp:386-402)
+    if (wu < consumed) hits += (unsigned long long)d.n;
     if (my_slot >= 0 && lane == 0) {
       const int slot = node * S + my_slot;
       sx[slot] = qx;

@@ -91,9 +91,11 @@ def build_library(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("trg_kernels.hip", "trg_kernels.h", "trg_engine.cpp",
                                              "host_index.h", "trg_bfs.inc", "trg_bfs_launch.inc",
                                              "trg_engine_bfs.inc", "trg_voxel.hip",
-                                             "map_order_sim.h")]
-    srcs.append(os.path.normpath(os.path.join(CSRC, "..", "..", "include", "trg_engine.h")))
-    stale = force or not os.path.exists(LIB_PATH)
+                                             "map_order_sim.h", "graph_json.h", "trg_pybind.cpp")]
+    for h in ("trg_engine.h", "trg_shim.hpp"):
+        srcs.append(os.path.normpath(os.path.join(CSRC, "..", "..", "include", h)))
+    import glob
+    stale = force or not os.path.exists(LIB_PATH) or not glob.glob(os.path.join(_HERE, "_trg_pybind*.so"))
     if not stale:
         t = os.path.getmtime(LIB_PATH)
         stale = any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
