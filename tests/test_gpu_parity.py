@@ -291,12 +291,15 @@ def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
     runs into the bound): the engine must take the level back (k_bfs_undo_commit), replay it on the
     host and continue on the device, and the graph must still equal the oracle's."""
     prm = dict(oa.MOUNTAIN, sample_num=10)
+    e0 = _engine(prm)
+    e0.set_sampler(21, 16)
+    e0.set_global_map(mountain_small)
+    e0.init_graph([15.0, 15.0, 0.0])
+    natural = e0.stats()["bfs_host_levels"]  # this cloud has one real nearest-node tie (level 71)
+    e0.close()
     e = _engine(prm)
     e.set_sampler(21, 16)
     e.set_option("keep_preclean", 1)
-    e.set_global_map(mountain_small)
-    e.init_graph([15.0, 15.0, 0.0])
-    natural = e.stats()["bfs_host_levels"]  # this cloud has one real nearest-node tie (level 71)
     e.set_option("debug_stall_level", 9)
     e.set_global_map(mountain_small)
     e.init_graph([15.0, 15.0, 0.0])

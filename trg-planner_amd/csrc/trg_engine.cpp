@@ -17,6 +17,7 @@
 #include <math.h>  // float overloads of atan2 etc. in the global namespace, as the reference has
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -336,6 +337,9 @@ struct TrgEngine {
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
+  // map points inside the queries of the level kernels of the last device build (instrumentation;
+  // counted per committed level, so discarded launches count nothing)
+  uint64_t lv_hits_sample = 0, lv_hits_spec = 0;
   TrgStats stats{};
 
   // goal state (trg.h:121-126)
@@ -1443,9 +1447,9 @@ void read_counters(TrgEngine *e) {
       ph += c.spec_hits;
       ties += c.nn_ties;
     }
-    e->stats.bytes_sample_kernel = 12ull * sh;
+    e->stats.bytes_sample_kernel = 12ull * (sh + e->lv_hits_sample);
     e->stats.bytes_edge_kernel = 12ull * eh;
-    e->stats.bytes_spec_kernel = 12ull * ph;
+    e->stats.bytes_spec_kernel = 12ull * (ph + e->lv_hits_spec);
     e->stats.map_nn_ties += ties;
   }
 }
@@ -1686,6 +1690,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     e->stats.ms_set_map_total = keep.ms_set_map_total;
   }
   HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
+  e->lv_hits_sample = e->lv_hits_spec = 0;
   const bool want_device = !e->step3 && e->use_device_bfs;
   if (!want_device) ensure_real_map(e);
   MapOrderSim sim_before;  // container history as of before this build (for the fallback)
@@ -1740,6 +1745,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     // reference kd-tree's shape): redo the build with the host replay, which handles those
     e->stats.bfs_fallbacks++;
     HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
+    e->lv_hits_sample = e->lv_hits_spec = 0;
     e->nodes_sim = sim_before;
     e->real_map_stale = stale_before;
     ensure_real_map(e);

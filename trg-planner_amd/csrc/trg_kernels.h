@@ -130,7 +130,12 @@ constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, no
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
   BFS_CTR_V = 0, BFS_CTR_MNEXT = 1, BFS_CTR_NCAND = 2, BFS_CTR_NUNC = 3, BFS_CTR_ERR = 4,
-  BFS_CTR_NBPOOL = 5, BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */, BFS_CTR_COUNT = 8
+  BFS_CTR_NBPOOL = 5, BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */,
+  BFS_CTR_NUNC1 = 8,  // uncertain gates of odd levels (the next level is expanded while the host
+                      // still looks at this one)
+  // statistics of the level just committed (k_level_commit)
+  BFS_CTR_LDRAWS = 9, BFS_CTR_LSAMPLES = 10, BFS_CTR_LHITS_S = 11, BFS_CTR_LHITS_E = 12,
+  BFS_CTR_COUNT = 16
 };
 enum : int {
   BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
@@ -172,9 +177,13 @@ struct BfsDev {
   // call log (one record per sample slot, in program order)
   int *call_n1, *call_n2, *call_status;
   float *call_w, *call_dist;
+  // level kernels (trg_level.inc)
+  unsigned long long *lv_tag;   // candidate hash: level tag << 32 | node-grid cell (payload: ht_slot/x/y)
+  int *hits_sample, *hits_spec; // per frontier node: map points inside its queries (instrumentation)
+  int *newid_of_call;           // node id created by call number i (set by k_level_commit)
   // counters
   int *ctrs;
-  unsigned long long *stats64;  // draws, samples, created, invalid, spec evaluations
+  unsigned long long *stats64;  // [6]: longest resolve wait
 };
 
 struct FinDev {
@@ -202,6 +211,19 @@ constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-reside
 void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
                         int V0, int ncand_bound, hipStream_t s, bool stall_test = false);
 void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
+// ---- one BFS level in three kernels (trg_level.inc) ---------------------------------------------
+constexpr int LEVEL_MAX_SAMPLES = 64;  // sample_num the level kernels support
+// expansion of the frontier nodes [node_base, count) (count_dev != nullptr: count is an upper
+// bound, the kernel takes min(count, *count_dev)); tag: hash tag of this level attempt (>= 1)
+void launch_level_expand(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
+                         int table_bits, uint32_t seed, uint32_t epoch, const BfsDev &B, int count,
+                         const int *count_dev, int node_base, int parity, int tag, DeviceCounters *ctr,
+                         hipStream_t s);
+// whether the level kernels can serve these parameters (window of the node grid, sample count)
+bool level_kernels_support(const QueryParams &p, float grid_cell);
+void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int new_state,
+                                 long long call_base, int V0, int tag, hipStream_t s,
+                                 bool stall_test = false);
 void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, const int *list, int count,
                        DeviceCounters *ctr, hipStream_t s);
 void launch_first_insert(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);

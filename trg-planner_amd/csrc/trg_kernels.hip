@@ -1648,11 +1648,13 @@ constexpr int SBOX = 10;     // box rows / columns of cells the tile can describ
 constexpr int SHCAP = 256;   // hits per disc kept for the median (denser discs: global fallback)
 
 struct SampleLds {
-  float x[STILE], y[STILE], z[STILE];
+  f2 xy[STILE];  // (x, y) interleaved: one 8-byte LDS read feeds the distance arithmetic
+  float z[STILE];
   int perm[STILE];
   int cs[SBOX][SBOX + 1];  // cs[row][col]: tile offset of the first point of box cell (row, col)
   float zb[SW][SHCAP];
   int bx0, by0, ncols, nrows, total;
+  int s_row[SBOX], row_off[SBOX + 1], row_len[SBOX];  // staging scratch
 };
 
 // isCollision + nearest map point of one disc, candidates read from the block tile
@@ -1675,8 +1677,9 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
       bool hit = false;
       float z = 0.0f, d2 = 0.0f;
       if (i < e) {
-        const float dx = L.x[i] - qx;
-        const float dy = L.y[i] - qy;
+        const f2 pt = L.xy[i];
+        const float dx = pt.x - qx;
+        const float dy = pt.y - qy;
         z = L.z[i];
         d2 = dx * dx + dy * dy;
         hit = d2 <= r2;
@@ -1735,48 +1738,12 @@ __device__ Disc sample_tile_disc(const MapView &m, const SampleLds &L, float *zb
   return out;
 }
 
-// One block per queued node: the rejection-sampling loop of expandGraph (trg.cpp:384-403).
-// Each round evaluates SW consecutive draws concurrently (one wave per draw); acceptance is
-// then decided in draw order, so the result equals the sequential loop's.
-__global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryParams p,
-                                                           const float *cos_t, const float *sin_t,
-                                                           int table_bits, uint32_t seed,
-                                                           uint32_t epoch, const float *node_xy,
-                                                           const int *node_id, int count,
-                                                           int *n_acc_out, int *n_draws_out,
-                                                           float *sx, float *sy, float *sz,
-                                                           DeviceCounters *ctr, const int *front,
-                                                           const float *gnx, const float *gny,
-                                                           int *mt_count, MapTieRec *mt_rec,
-                                                           const int *count_dev, int node_base) {
-  __shared__ SampleLds L;
-  __shared__ int r_col[2][SW];
-  __shared__ unsigned long long r_hits[SW];
-  __shared__ int r_ties[SW];
-  __shared__ int s_row[SBOX], row_off[SBOX + 1], row_len[SBOX];
-  // count_dev: the frontier size lives on the device (launch issued before the host knew it; the
-  // grid is an upper bound), node_base: first node of a follow-up launch
-  const int node = (int)blockIdx.x + node_base;
-  if (count_dev) count = min(count, *count_dev);
-  if (node >= count) return;
+// Stage the box of all possible trial discs of one queued node into the block tile (all threads of
+// the workgroup call this; contains barriers).  Returns false when the box does not fit: the caller
+// then uses the global-memory queries.
+__device__ bool stage_sample_tile(const MapView &m, const QueryParams &p, float px, float py,
+                                  SampleLds &L) {
   const int tid = threadIdx.x;
-  const int w = tid >> 6;
-  const int lane = lane_id();
-  // two addressing modes: chunk arrays (host replay) or frontier ids into the device node arrays
-  float px, py;
-  uint32_t id;
-  if (front) {
-    const int g = front[node];
-    px = gnx[g];
-    py = gny[g];
-    id = (uint32_t)g;
-  } else {
-    px = node_xy[2 * node];
-    py = node_xy[2 * node + 1];
-    id = (uint32_t)node_id[node];
-  }
-
-  // ---- stage the box of all possible discs of this node --------------------------------------
   const CellRange box = cells_for(m, px, py, p.expand_dist + p.robot_size * 1.002f + 1e-5f);
   const int ncols = box.cx1 - box.cx0 + 1, nrows = box.cy1 - box.cy0 + 1;
   bool use_tile = ncols <= SBOX && nrows <= SBOX;
@@ -1805,17 +1772,17 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
       }
       const int a = c_hi >= c_lo ? L.cs[row][c_lo] : L.cs[row][0];
       const int bnd = c_hi >= c_lo ? L.cs[row][c_hi + 1] : L.cs[row][0];
-      s_row[row] = a;
-      row_len[row] = bnd - a;
+      L.s_row[row] = a;
+      L.row_len[row] = bnd - a;
     }
     __syncthreads();
     if (tid == 0) {
       int acc = 0;
       for (int row = 0; row < nrows; ++row) {
-        row_off[row] = acc;
-        acc += row_len[row];
+        L.row_off[row] = acc;
+        acc += L.row_len[row];
       }
-      row_off[nrows] = acc;
+      L.row_off[nrows] = acc;
       L.total = acc;
       L.bx0 = box.cx0;
       L.by0 = box.cy0;
@@ -1829,10 +1796,12 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
     const int total = L.total;
     for (int idx = tid; idx < total; idx += SW * WAVE) {
       int row = 0;
-      for (int rr = 1; rr < nrows; ++rr) row += (idx >= row_off[rr]);
-      const int src = s_row[row] + (idx - row_off[row]);
-      L.x[idx] = m.x[src];
-      L.y[idx] = m.y[src];
+      for (int rr = 1; rr < nrows; ++rr) row += (idx >= L.row_off[rr]);
+      const int src = L.s_row[row] + (idx - L.row_off[row]);
+      f2 pt;
+      pt.x = m.x[src];
+      pt.y = m.y[src];
+      L.xy[idx] = pt;
       L.z[idx] = m.z[src];
       L.perm[idx] = m.perm[src];
     }
@@ -1842,11 +1811,56 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
     if (tid < ncs) {
       const int row = tid / (ncols + 1), col = tid - row * (ncols + 1);
       // cells left / right of the staged columns are empty ranges at the row's start / end
-      const int len = row_off[row + 1] - row_off[row];
-      L.cs[row][col] = row_off[row] + min(max(L.cs[row][col] - s_row[row], 0), len);
+      const int len = L.row_off[row + 1] - L.row_off[row];
+      L.cs[row][col] = L.row_off[row] + min(max(L.cs[row][col] - L.s_row[row], 0), len);
     }
     __syncthreads();
   }
+
+  return use_tile;
+}
+
+// One block per queued node: the rejection-sampling loop of expandGraph (trg.cpp:384-403).
+// Each round evaluates SW consecutive draws concurrently (one wave per draw); acceptance is
+// then decided in draw order, so the result equals the sequential loop's.
+__global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryParams p,
+                                                           const float *cos_t, const float *sin_t,
+                                                           int table_bits, uint32_t seed,
+                                                           uint32_t epoch, const float *node_xy,
+                                                           const int *node_id, int count,
+                                                           int *n_acc_out, int *n_draws_out,
+                                                           float *sx, float *sy, float *sz,
+                                                           DeviceCounters *ctr, const int *front,
+                                                           const float *gnx, const float *gny,
+                                                           int *mt_count, MapTieRec *mt_rec,
+                                                           const int *count_dev, int node_base) {
+  __shared__ SampleLds L;
+  __shared__ int r_col[2][SW];
+  __shared__ unsigned long long r_hits[SW];
+  __shared__ int r_ties[SW];
+  // count_dev: the frontier size lives on the device (launch issued before the host knew it; the
+  // grid is an upper bound), node_base: first node of a follow-up launch
+  const int node = (int)blockIdx.x + node_base;
+  if (count_dev) count = min(count, *count_dev);
+  if (node >= count) return;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6;
+  const int lane = lane_id();
+  // two addressing modes: chunk arrays (host replay) or frontier ids into the device node arrays
+  float px, py;
+  uint32_t id;
+  if (front) {
+    const int g = front[node];
+    px = gnx[g];
+    py = gny[g];
+    id = (uint32_t)g;
+  } else {
+    px = node_xy[2 * node];
+    py = node_xy[2 * node + 1];
+    id = (uint32_t)node_id[node];
+  }
+
+  const bool use_tile = stage_sample_tile(m, p, px, py, L);
 
   const int S = p.sample_num;
   const int max_trial_sample = 1000;
@@ -1950,6 +1964,7 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
 }
 
 #include "trg_bfs.inc"
+#include "trg_level.inc"
 
 inline int blocks_for(size_t n, int per_block, int cap) {
   size_t b = (n + per_block - 1) / per_block;
