@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <cstddef>
 #include <chrono>
 #include <cstdio>
 #include <cstring>

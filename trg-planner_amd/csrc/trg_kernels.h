@@ -125,12 +125,13 @@ void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, i
                        float *mid, int *status, int *n_pts, float *weight, float *dist,
                        DeviceCounters *ctr, hipStream_t s);
 
-// ---- device-resident BFS (trg_bfs.inc) ------------------------------------------------------------
+// ---- device-resident BFS (trg_bfs.inc, trg_level.inc) -------------------------------------------------
 constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, nodes are >= robot_size apart)
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
   BFS_CTR_V = 0, BFS_CTR_MNEXT = 1, BFS_CTR_NCAND = 2, BFS_CTR_NUNC = 3, BFS_CTR_ERR = 4,
-  BFS_CTR_NBPOOL = 5, BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */,
+  BFS_CTR_DONE = 5,   // k_level_commit workgroups that have finished (the last one publishes)
+  BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */,
   BFS_CTR_NUNC1 = 8,  // uncertain gates of odd levels (the next level is expanded while the host
                       // still looks at this one)
   // statistics of the level just committed (k_level_commit)
@@ -140,50 +141,81 @@ enum : int {
 enum : int {
   BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
   BFS_ERR_HASH = 16, BFS_ERR_LEVEL_TOO_BIG = 32, BFS_ERR_CLEAN = 64,
-  BFS_ERR_STALL = 128  // k_bfs_resolve's bounded wait ran out: the level is replayed on the host
+  BFS_ERR_STALL = 128  // k_level_resolve's bounded wait ran out: the level is replayed on the host
 };
 enum : int { CALL_NONE = -2, CALL_PENDING = -1 };
+
+// One cell of the node hash grid (cell = robot_size): everything a probe needs in one 64-byte line.
+struct alignas(64) GridCell {
+  int cnt;
+  int id[GRID_SLOTS];
+  float x[GRID_SLOTS], y[GRID_SLOTS];
+  int pad[3];
+};
+// Everything the level kernels keep per sample slot (slot = queue position * S + j), 64 bytes.
+struct alignas(16) SlotRec {
+  float x, y, z;   // accepted sample: position and elevation of the nearest map point
+  float d0sq;      // squared distance to the nearest node that existed before the level
+  int nn0;         // that node (-1: none in reach)
+  int cls;         // 0 unused slot, 1 a pre-level node within robot_size, 2 candidate for a new node
+  int status;      // speculative parent edge (candidates): EDGE_* code and flags
+  float dist;      //   its length
+  float cov[6];    //   covariance of its gather (xx xy xz yy yz zz), or cov[0] = weight when w_given
+  int w_given;     //   1: the weight itself is stored (host re-evaluation after a map tie)
+  int pad;
+};
+struct alignas(16) NodeRec {  // per queued node of a level, 32 bytes
+  int n_acc, n_draws;         // accepted samples, draws made
+  int hits_sample, hits_spec; // map points inside its sampling discs / speculative-edge queries
+  unsigned cand_lo, cand_hi;  // bit j: accepted sample j is a candidate
+  int pad[2];
+};
+struct alignas(16) HashEnt {  // candidate hash of a level: node-grid cell -> candidate
+  unsigned long long tagcell; // level tag << 32 | cell; entries of other levels count as empty
+  int slot;
+  int pad;
+  float x, y;
+  int pad2[2];
+};
+struct alignas(16) NodeCov {  // what the edge to a node created by the BFS still needs: its weight
+  float cov[6];               // is computed after the level loop (k_node_weights)
+  int w_given;
+  int call;                   // the wireEdge call that created the node
+};
 
 struct BfsDev {
   // node store (creation order) and its hash grid
   float *nx, *ny, *nz;
   int *nstate;
+  NodeCov *ncov;
   int vcap;
-  int *gcnt, *gslots;
-  float *gsx, *gsy;  // positions of the nodes in gslots (saves a dependent load per probe)
-  float gx0, gy0, ginv, gcell;
+  GridCell *gcell;
+  float gx0, gy0, ginv, gcell_size;
   int GW, GH;
   // frontier ping-pong
   int *front_cur, *front_next;
   int fcap;
-  // per frontier node
-  int *n_acc, *n_draws;
-  // per sample slot (fcap * S)
-  float *sx, *sy, *sz, *d0sq;
-  int *nn0, *cls, *cand_off;
-  // per candidate
-  int *cand_slot, *c_status, *c_outcome, *c_target, *c_newid;
-  int *newnode_slot;  // slot of the sample that created node V0 + k in the current level
-  int *blk_tot;       // per 256-candidate group: created | valid << 16 (k_bfs_resolve -> k_bfs_commit)
-  float *mid, *c_weight, *c_dist;
-  // uncertain slope gates for the host
+  // level records (two sets, by level parity)
+  NodeRec *node_rec;
+  SlotRec *slot_rec;
+  int *c_outcome;   // per slot: resolve outcome (polled across workgroups)
+  HashEnt *lv_hash;
+  int ht_size;
+  int *blk_tot;     // per RW-slot group: created | valid << 16 (k_level_resolve -> k_level_commit)
+  // deferred edge evaluation scratch
+  float *mid;
+  // uncertain slope gates for the host (2 x BFS_UNC_CAP, by level parity)
   int *unc_list;
   float *unc_rec;
   MapTieRec *mt_rec;  // 2 x MAPTIE_CAP records (level parity), counts in ctrs[BFS_CTR_NMAPTIE + parity]
-  // candidate hash of the level
-  int *ht_key, *ht_val, *ht_slot;
-  float *ht_x, *ht_y;
-  int ht_size;
   // call log (one record per sample slot, in program order)
   int *call_n1, *call_n2, *call_status;
   float *call_w, *call_dist;
-  // level kernels (trg_level.inc)
-  unsigned long long *lv_tag;   // candidate hash: level tag << 32 | node-grid cell (payload: ht_slot/x/y)
-  int *hits_sample, *hits_spec; // per frontier node: map points inside its queries (instrumentation)
-  int *newid_of_call;           // node id created by call number i (set by k_level_commit)
+  int *newid_of_call;  // node id created by call number i (set by k_level_commit)
   // counters
   int *ctrs;
-  unsigned long long *stats64;  // [6]: longest resolve wait
+  int *host_ctrs;      // pinned host copy of ctrs + stamp, written by k_level_commit (may be null)
+  unsigned long long *stats64;  // [6]: longest resolve wait; [8..13]: expand phase cycles (profiling)
 };
 
 struct FinDev {
@@ -197,19 +229,6 @@ struct FinDev {
 };
 
 void launch_bfs_insert_nodes(const BfsDev &B, int first, int count, hipStream_t s);
-void launch_bfs_sample(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
-                       int table_bits, uint32_t seed, uint32_t epoch, const BfsDev &B, int count,
-                       DeviceCounters *ctr, hipStream_t s, const int *count_dev, int node_base,
-                       int parity);
-// classify + candidate scan/fill + speculative parent edges (ends where the host must look at
-// BFS_CTR_NUNC); flag / scan_tmp: scratch of count*S+1 and count*S/2048+4 ints
-void launch_bfs_level_a(const MapView &m, QueryParams p, const BfsDev &B, int count, int *flag,
-                        int *scan_tmp, DeviceCounters *ctr, hipStream_t s, hipEvent_t spec_begin,
-                        hipEvent_t spec_end);
-// neighbour lists + resolve + call emission
-constexpr int BFS_MAX_LEVEL_CANDS = 128 * 1024;  // resolve grid stays co-resident (<= 512 groups)
-void launch_bfs_level_b(const BfsDev &B, QueryParams p, int count, int new_state, long long call_base,
-                        int V0, int ncand_bound, hipStream_t s, bool stall_test = false);
 void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
 // ---- one BFS level in three kernels (trg_level.inc) ---------------------------------------------
 constexpr int LEVEL_MAX_SAMPLES = 64;  // sample_num the level kernels support
@@ -221,9 +240,12 @@ void launch_level_expand(const MapView &m, QueryParams p, const float *cos_t, co
                          hipStream_t s);
 // whether the level kernels can serve these parameters (window of the node grid, sample count)
 bool level_kernels_support(const QueryParams &p, float grid_cell);
+// stamp: value k_level_commit leaves in host_ctrs[BFS_CTR_COUNT] once the level's counters are there
 void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int new_state,
-                                 long long call_base, int V0, int tag, hipStream_t s,
+                                 long long call_base, int V0, int tag, int stamp, hipStream_t s,
                                  bool stall_test = false);
+// weights of the edges to the nodes [1, V) the BFS created (covariance -> SVD -> weight)
+void launch_node_weights(const BfsDev &B, int V, hipStream_t s);
 void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, const int *list, int count,
                        DeviceCounters *ctr, hipStream_t s);
 void launch_first_insert(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);

@@ -1794,7 +1794,7 @@ __device__ bool stage_sample_tile(const MapView &m, const QueryParams &p, float 
   }
   if (use_tile) {
     const int total = L.total;
-    for (int idx = tid; idx < total; idx += SW * WAVE) {
+    for (int idx = tid; idx < total; idx += (int)blockDim.x) {
       int row = 0;
       for (int rr = 1; rr < nrows; ++rr) row += (idx >= L.row_off[rr]);
       const int src = L.s_row[row] + (idx - L.row_off[row]);
