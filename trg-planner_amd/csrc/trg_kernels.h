@@ -130,7 +130,7 @@ constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, no
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
   BFS_CTR_V = 0, BFS_CTR_MNEXT = 1, BFS_CTR_NCAND = 2, BFS_CTR_NUNC = 3, BFS_CTR_ERR = 4,
-  BFS_CTR_DONE = 5,   // k_level_commit workgroups that have finished (the last one publishes)
+  BFS_CTR_DONE = 5,   // spare on the device; in the host copy: the stamp of the level (as word 15)
   BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */,
   BFS_CTR_NUNC1 = 8,  // uncertain gates of odd levels (the next level is expanded while the host
                       // still looks at this one)
@@ -233,16 +233,17 @@ void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
 // ---- one BFS level in three kernels (trg_level.inc) ---------------------------------------------
 constexpr int LEVEL_MAX_SAMPLES = 64;  // sample_num the level kernels support
 // expansion of the frontier nodes [node_base, count) (count_dev != nullptr: count is an upper
-// bound, the kernel takes min(count, *count_dev)); tag: hash tag of this level attempt (>= 1)
+// bound, the kernel takes min(count, *count_dev)); tag: hash tag of this level attempt (>= 1);
+// pub_stamp != 0: the launch first hands B.ctrs (the counters of the level committed just before
+// it in the stream) to the host: B.host_ctrs[0..15], words 5 and 15 = pub_stamp
 void launch_level_expand(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
                          int table_bits, uint32_t seed, uint32_t epoch, const BfsDev &B, int count,
-                         const int *count_dev, int node_base, int parity, int tag, DeviceCounters *ctr,
-                         hipStream_t s);
+                         const int *count_dev, int node_base, int parity, int tag, int pub_stamp,
+                         DeviceCounters *ctr, hipStream_t s);
 // whether the level kernels can serve these parameters (window of the node grid, sample count)
 bool level_kernels_support(const QueryParams &p, float grid_cell);
-// stamp: value k_level_commit leaves in host_ctrs[BFS_CTR_COUNT] once the level's counters are there
 void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int new_state,
-                                 long long call_base, int V0, int tag, int stamp, hipStream_t s,
+                                 long long call_base, int V0, int tag, hipStream_t s,
                                  bool stall_test = false);
 // weights of the edges to the nodes [1, V) the BFS created (covariance -> SVD -> weight)
 void launch_node_weights(const BfsDev &B, int V, hipStream_t s);
