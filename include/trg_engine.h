@@ -41,7 +41,12 @@ typedef enum TrgStatus {
 /* Graph / map selector: reference trgMap_ keys "global" / "local" (trg.h:113-119).
  * TRG_KIND_PRECLEAN is build-side instrumentation: the global graph as it stood right before
  * the last cleanGraph(), ids == creation order (used by the parity tests). */
-typedef enum TrgKind { TRG_KIND_GLOBAL = 0, TRG_KIND_LOCAL = 1, TRG_KIND_PRECLEAN = 2 } TrgKind;
+typedef enum TrgKind {
+  TRG_KIND_GLOBAL = 0,
+  TRG_KIND_LOCAL = 1,
+  TRG_KIND_PRECLEAN = 2,
+  TRG_KIND_STITCHED = 3 /* tiled builds: this tile's rows of the stitched global graph (global ids) */
+} TrgKind;
 
 /* Node states: reference TRG::NodeState, trg.h:27-31 */
 enum { TRG_NODE_VALID = 0, TRG_NODE_INVALID = -1, TRG_NODE_FRONTIER = 1 };
@@ -246,6 +251,28 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
  * node creation to the core region [x0,x1) x [y0,y1) -- a sample outside it counts as a rejected
  * draw -- and give the tile its own sampler epoch.  core_xyxy == NULL restores the whole plane. */
 TrgStatus trg_engine_set_tile(TrgEngine *e, const float core_xyxy[4], uint32_t epoch);
+/* ---- tiled builds: the boundary stitch (an extension; rule: trg_planner/tiled.py) --
+ * Three steps with one exchange between each (all-gather-v of DEVICE buffers over RCCL, done by the
+ * caller; tile index == rank).  d_* arguments are device pointers owned by the caller. */
+typedef struct TrgBoundaryRec { int32_t local_id; float x, y, z; } TrgBoundaryRec;          /* 16 bytes */
+typedef struct TrgCrossEdge { int32_t tile_a, id_a, tile_b, id_b; float weight, dist; } TrgCrossEdge; /* 24 */
+/* 1: the nodes of this tile closer than expand_dist to a core side shared with another tile of the
+ * cols x rows grid, ascending local id.  d_rec may be NULL to ask for the count only. */
+TrgStatus trg_engine_stitch_boundary(TrgEngine *e, const float core_xyxy[4], int32_t cols, int32_t rows,
+                                     int32_t tile, TrgBoundaryRec *d_rec, int32_t cap, int32_t *n_out);
+/* 2: the cross edges this tile owns: every pair (a of this tile, b of a HIGHER tile) of the gathered
+ * records (all tiles concatenated in tile order, rec_offsets[ntiles + 1] on the host) with fp32 planar
+ * distance < expand_dist (the test of trg.cpp:414) whose wireEdge position-only part (trg.cpp:269-363)
+ * succeeds on this tile's map; order (other tile, a, b). */
+TrgStatus trg_engine_stitch_cross(TrgEngine *e, int32_t tile, int32_t ntiles, const TrgBoundaryRec *d_all_rec,
+                                  const int32_t *rec_offsets, TrgCrossEdge *d_edges, int32_t cap,
+                                  int32_t *n_out);
+/* 3: this tile's rows of the global graph from ALL tiles' cross edges (any order): local edges with
+ * global ids (node_offsets[tile] + local id; node_offsets[ntiles + 1] = exclusive prefix of the tiles'
+ * node counts), then the row's cross edges ordered by the global id of their other end.  Read the
+ * result with trg_engine_export_csr(TRG_KIND_STITCHED); creation_id holds the rows' global ids. */
+TrgStatus trg_engine_stitch_assemble(TrgEngine *e, int32_t tile, int32_t ntiles, const int32_t *node_offsets,
+                                     const TrgCrossEdge *d_all_edges, int32_t n_edges);
 /* why the last build fell back from the device path to the host replay ("" if it did not) */
 const char *trg_engine_fallback_reason(const TrgEngine *e);
 

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Full-size parity run (BASELINE config 3: 10 M points, S=16): the engine's graph against the CPU
-oracle's, node by node.  The oracle needs several minutes at this size, so this is a one-off
-evidence run (result written to gpurun_out/ and copied to profiles/), not part of the test suite.
+oracle's, node by node.  The oracle needs several minutes at this size, so it runs HERE, once; what
+it found is written as a digest of the ORACLE's graph (tests/golden/c3_digest.json +
+c3_w_sample.npz) that tests/test_gpu_c3_fullsize.py compares every later engine build against.
 
 usage: python scripts/fullscale_parity.py [nx ny]   (default 3200 3125)
 """
+import hashlib
 import json
 import os
 import sys
@@ -84,3 +86,39 @@ compare(ge_pre, go_pre, "preclean")
 compare(ge, go, "global")
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))
+
+
+# ---- digest of the ORACLE's cleaned graph (the golden vector of the full-size test) ----------------
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+rng = np.random.default_rng(20250418)
+sample_idx = np.sort(rng.choice(go.E, size=min(go.E, 1 << 16), replace=False)).astype(np.int64)
+digest = {
+    "workload": f"C3: synth.mountain_tile(0, {nx}, 0, {ny}, seed=20250418), mountain.yaml, sampleNum=16, "
+                f"sampler seed 7 / 16 bits, start = terrain centre",
+    "made_by": "scripts/fullscale_parity.py (oracle/trg_oracle.cpp, kd-tree = reference kdtree.c)",
+    "V": int(go.V), "E": int(go.E),
+    "sha256": {"rowptr": sha(go.rowptr.astype(np.int32)), "col": sha(go.col.astype(np.int32)),
+               "state": sha(go.state.astype(np.int32)), "xyz": sha(go.xyz.astype(np.float32)),
+               "dist": sha(go.dist.astype(np.float32)), "cid": sha(go.cid.astype(np.int32))},
+    "w_zero_edges": int((go.w == 0).sum()), "w_sum": float(go.w.astype(np.float64).sum()),
+    "oracle_seconds": {"index": t_index, "init_graph": t_oracle},
+}
+if ge.E == go.E and ge.V == go.V:
+    we, wo = ge.w.astype(np.float64), go.w.astype(np.float64)
+    hi = np.maximum(we, wo)
+    flip = ((we == 0) != (wo == 0)) & (hi >= 0.1 - 1e-5) & (hi <= 0.1 + 1e-5)
+    src = np.repeat(np.arange(go.V, dtype=np.int64), np.diff(go.rowptr))
+    digest["engine_at_digest_time"] = {
+        "clamp_flip_edges": [[int(src[i]), int(go.col[i])] for i in np.nonzero(flip)[0]],
+        "others_over_1e-5": int(((np.abs(we - wo) > 1e-5) & ~flip).sum()),
+        "max_abs_dw_excluding_flips": float(np.abs(we - wo)[~flip].max()),
+    }
+gold = os.path.join(ROOT, "gpurun_out", "golden")
+os.makedirs(gold, exist_ok=True)
+json.dump(digest, open(os.path.join(gold, f"c3_digest_{nx}x{ny}.json"), "w"), indent=1)
+np.savez_compressed(os.path.join(gold, f"c3_w_sample_{nx}x{ny}.npz"), idx=sample_idx.astype(np.int32),
+                    w=go.w[sample_idx].astype(np.float32))
+print("digest written to", gold)

@@ -1,0 +1,59 @@
+"""GPU: BASELINE config 3 at its real size -- 10 M-point synthetic terrain, mountain.yaml, sampleNum 16
+-- against the golden digest of the CPU oracle's graph (tests/golden/c3_digest.json, made once by
+scripts/fullscale_parity.py on a GPU box: the oracle needs ~2.5 minutes of host time at this size).
+
+Bit-exact: V', E', rowptr, col, state, node xyz, edge dist, creation ids (sha256 of the arrays).
+Weights: a fixed random sample of 65 536 edges against the oracle's values, every one within 1e-5
+(clamp flips counted apart and bounded by what the digest run saw); zero-weight edge count and the
+weight sum of the whole graph against the oracle's."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sha(a, dt):
+    return hashlib.sha256(np.ascontiguousarray(a.astype(dt, copy=False)).tobytes()).hexdigest()
+
+
+def test_c3_fullsize_against_oracle_digest(synth):
+    import trg_planner
+    from conftest import weight_report
+    from test_gpu_scale import _invariants
+    dg = json.load(open(os.path.join(GOLD, "c3_digest.json")))
+    ws = np.load(os.path.join(GOLD, "c3_w_sample.npz"))
+    nx, ny = 3200, 3125
+    cloud = synth.mountain_tile(0, nx, 0, ny, seed=20250418)
+    assert cloud.shape[0] == 10_000_000
+    prm = dict(expand_dist=0.6, robot_size=0.3, sample_num=16, height_threshold=0.16,
+               collision_threshold=0.1, update_collision_threshold=0.5, safety_factor=3.0,
+               goal_tolerance=0.8)
+    e = trg_planner.Engine(**prm)
+    e.set_sampler(7, 16)
+    e.set_global_map(cloud)
+    del cloud
+    e.init_graph([nx * 0.05, ny * 0.05, 0.0])
+    st = e.stats()
+    assert st["used_device_bfs"] == 1 and st["bfs_fallbacks"] == 0, e.fallback_reason
+    g = e.graph("global")
+    assert (g.V, g.E) == (dg["V"], dg["E"]), (g.V, g.E)
+    for name, arr, dt in (("rowptr", g.rowptr, np.int32), ("col", g.col, np.int32),
+                          ("state", g.state, np.int32), ("xyz", g.xyz, np.float32),
+                          ("dist", g.dist, np.float32), ("cid", g.cid, np.int32)):
+        assert _sha(arr, dt) == dg["sha256"][name], name
+    # weights: the sampled edges one by one, the whole graph through two aggregates
+    flips, others, mx = weight_report(g.w[ws["idx"]], ws["w"], 1e-5)
+    assert others == 0, (others, mx)
+    known_flips = len(dg.get("engine_at_digest_time", {}).get("clamp_flip_edges", []))
+    assert flips <= known_flips, (flips, known_flips)
+    zero = int((g.w == 0).sum())
+    assert abs(zero - dg["w_zero_edges"]) <= 2 * max(known_flips, 1), (zero, dg["w_zero_edges"])
+    wsum = float(g.w.astype(np.float64).sum())
+    # every edge within 1e-5 would allow E * 1e-5; the digest run measured 2e-6 at worst
+    assert abs(wsum - dg["w_sum"]) <= g.E * 3e-6 + 0.2 * max(known_flips, 1), (wsum, dg["w_sum"])
+    _invariants(g, prm["expand_dist"])

@@ -258,6 +258,7 @@ struct EdgeBatch {
 };
 
 struct BfsBuffers;  // device-resident BFS state (trg_engine_bfs.inc)
+struct StitchBufs;  // scratch of the tile-boundary stitch (trg_engine_stitch.inc)
 
 }  // namespace
 
@@ -327,6 +328,9 @@ struct TrgEngine {
   unsigned long long *mt_key_d = nullptr, *mt_key_h = nullptr;
 
   Csr csr_global, csr_pre, csr_local;
+  Csr csr_stitched;              // tiled builds: this tile's rows of the stitched global graph
+  bool dev_csr_valid = false;    // the cleaned global CSR of the last device build is still in HBM
+  StitchBufs *stitch = nullptr;
   bool keep_preclean = false;    // instrumentation: snapshot the graph before cleanGraph
   bool use_device_bfs = true;    // device-resident BFS when expandGraph's step 3 is disabled
   bool pool_valid = true;        // e->edges mirrors csr_global
@@ -865,6 +869,7 @@ TrgStatus edges_sync(TrgEngine *e, DevMap &m, const float *p1, const float *p2, 
 
 // ---- graph state helpers -----------------------------------------------------------------------
 void reset_graph_global(TrgEngine *e) {
+  e->dev_csr_valid = false;
   e->nx.clear();
   e->ny.clear();
   e->nz.clear();
@@ -1547,6 +1552,7 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
   e->step3 = (e->prm.expand_dist - e->prm.robot_size) < 0.25 * e->prm.expand_dist;
   e->device_ok = true;
   e->bfs = new BfsBuffers();
+  e->stitch = new StitchBufs();
   if (const char *env = getenv("TRG_REPLAY")) e->use_device_bfs = std::string(env) != "host";
   reset_graph_global(e);
   return TRG_OK;
@@ -1592,6 +1598,10 @@ void trg_engine_destroy(TrgEngine *e) {
     if (e->bfs) {
       e->bfs->release();
       delete e->bfs;
+    }
+    if (e->stitch) {
+      e->stitch->release();
+      delete e->stitch;
     }
     free_pinned(e->sy_in);
     free_pinned(e->sy_in2);
@@ -1830,6 +1840,7 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   TrgStatus st = ensure_sampler(e, nullptr);
   if (st != TRG_OK) return st;
   e->epoch++;
+  e->dev_csr_valid = false;
   ensure_real_map(e);
   ensure_pool(e);
   ensure_host_grid(e);
@@ -1908,6 +1919,8 @@ TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out) {
     if (e->pool_valid && (c->rowptr.empty() || c->state.size() != e->nx.size())) snapshot_csr(e, *c);
   } else if (kind == TRG_KIND_PRECLEAN) {
     c = &e->csr_pre;
+  } else if (kind == TRG_KIND_STITCHED) {
+    c = &e->csr_stitched;
   } else {
     // local graph: the global rows of the local member nodes
     c = &e->csr_local;
@@ -2329,3 +2342,5 @@ TrgStatus trg_engine_debug_map_index(TrgEngine *e, TrgKind map, float *x, float 
 }
 
 }  // extern "C"
+
+#include "trg_engine_stitch.inc"

@@ -258,4 +258,31 @@ void launch_fin_clean(const FinDev &F, const BfsDev &B, const int *new2old, cons
                       int *deg_new, int *rowptr_new, int *scan_tmp, int *col, float *w, float *dist,
                       float *xyz, int *state, hipStream_t s);
 
+// ---- tile-boundary stitch of the tiled build (trg_stitch.inc) ----------------------------------------
+struct StitchRec {  // a boundary node: local id and position (16 bytes; layout of TrgBoundaryRec)
+  int id;
+  float x, y, z;
+};
+struct StitchEdge {  // a cross edge (24 bytes; layout of TrgCrossEdge)
+  int tile_a, id_a, tile_b, id_b;
+  float weight, dist;
+};
+constexpr int STITCH_MAX_TILES = 64;
+// sides: bit 0 left, 1 right, 2 bottom, 3 top side of the core has a neighbouring tile
+void launch_stitch_boundary(const float *d_xyz, int V, const float core[4], int sides, float d, int *flag,
+                            int *off, int *scan_tmp, StitchRec *rec, int cap, hipStream_t s);
+void launch_stitch_pairs(const StitchRec *all, const int *rec_offsets, int tile, int ntiles, float d,
+                         int pass, int *cnt, const int *off, int *pair_a, int *pair_b, hipStream_t s);
+void launch_stitch_pair_points(const StitchRec *all, const int *pair_a, const int *pair_b, int n,
+                               float *p1, float *p2, hipStream_t s);
+void launch_stitch_edge_select(const StitchRec *all, const int *rec_offsets, int tile, int ntiles,
+                               const int *pair_a, const int *pair_b, const int *status,
+                               const float *weight, const float *dist, int n, int *flag, int *off,
+                               int *scan_tmp, int *n_unc, StitchEdge *out, int cap, hipStream_t s);
+void launch_stitch_assemble(const StitchEdge *edges, int n_edges, int tile, int ntiles,
+                            const int *node_offsets, const int *rowptr, const int *col, const float *w,
+                            const float *dist, int V, int *extra, int *deg, int *rowptr_new,
+                            int *scan_tmp, int *fill, int *col_new, float *w_new, float *dist_new,
+                            int phase, hipStream_t s);
+
 }  // namespace trg

@@ -2066,5 +2066,6 @@ void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, i
 size_t edge_mid_floats(size_t edges) { return edges * MID_STRIDE; }
 
 #include "trg_bfs_launch.inc"
+#include "trg_stitch.inc"
 
 }  // namespace trg

@@ -15,8 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.path.join(CSRC, "libtrg_engine.so")
 
-KIND_GLOBAL, KIND_LOCAL, KIND_PRECLEAN = 0, 1, 2
-_KINDS = {"global": KIND_GLOBAL, "local": KIND_LOCAL, "preclean": KIND_PRECLEAN}
+KIND_GLOBAL, KIND_LOCAL, KIND_PRECLEAN, KIND_STITCHED = 0, 1, 2, 3
+_KINDS = {"global": KIND_GLOBAL, "local": KIND_LOCAL, "preclean": KIND_PRECLEAN,
+          "stitched": KIND_STITCHED}
 
 STATUS_NAMES = {0: "TRG_OK", 1: "TRG_ERR_INVALID_ARG", 2: "TRG_ERR_NO_MAP", 3: "TRG_ERR_NO_ROOT",
                 4: "TRG_ERR_DEVICE", 5: "TRG_ERR_NO_GRAPH", 6: "TRG_ERR_NOT_FOUND",
@@ -83,6 +84,7 @@ EXPORTS = [
     "trg_engine_debug_map_index", "trg_engine_set_option", "trg_engine_fallback_reason",
     "trg_engine_check_reached", "trg_engine_check_replan", "trg_engine_set_tile",
     "trg_engine_voxel_filter", "trg_engine_plan_batch",
+    "trg_engine_stitch_boundary", "trg_engine_stitch_cross", "trg_engine_stitch_assemble",
 ]
 
 
@@ -153,6 +155,9 @@ def load_library():
     L.trg_engine_check_replan.argtypes = [vp, fp, fp, C.c_int32]
     L.trg_engine_check_replan.restype = C.c_int32
     L.trg_engine_set_tile.argtypes = [vp, fp, C.c_uint32]
+    L.trg_engine_stitch_boundary.argtypes = [vp, fp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, ip]
+    L.trg_engine_stitch_cross.argtypes = [vp, C.c_int32, C.c_int32, vp, ip, vp, C.c_int32, ip]
+    L.trg_engine_stitch_assemble.argtypes = [vp, C.c_int32, C.c_int32, ip, vp, C.c_int32]
     L.trg_engine_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.trg_engine_fallback_reason.argtypes = [vp]
     L.trg_engine_fallback_reason.restype = C.c_char_p
@@ -230,6 +235,27 @@ class Engine:
         else:
             c = np.ascontiguousarray(core_xyxy, dtype=np.float32)
             self._chk(self.L.trg_engine_set_tile(self.h, _f(c), int(epoch)))
+
+    # ---- tiled builds: boundary stitch (device buffers = torch tensors' data_ptr()) -------------------
+    def stitch_boundary(self, core_xyxy, cols, rows, tile, rec_ptr=None, cap=0):
+        """Number of boundary nodes; with rec_ptr (device, cap x 16 bytes) also their records."""
+        c = np.ascontiguousarray(core_xyxy, dtype=np.float32)
+        n = C.c_int32(0)
+        self._chk(self.L.trg_engine_stitch_boundary(self.h, _f(c), cols, rows, tile,
+                                                    C.c_void_p(rec_ptr or 0), cap, C.byref(n)))
+        return n.value
+
+    def stitch_cross(self, tile, ntiles, all_rec_ptr, rec_offsets, edges_ptr=None, cap=0):
+        off = np.ascontiguousarray(rec_offsets, dtype=np.int32)
+        n = C.c_int32(0)
+        self._chk(self.L.trg_engine_stitch_cross(self.h, tile, ntiles, C.c_void_p(all_rec_ptr or 0), _i(off),
+                                                 C.c_void_p(edges_ptr or 0), cap, C.byref(n)))
+        return n.value
+
+    def stitch_assemble(self, tile, ntiles, node_offsets, all_edges_ptr, n_edges):
+        off = np.ascontiguousarray(node_offsets, dtype=np.int32)
+        self._chk(self.L.trg_engine_stitch_assemble(self.h, tile, ntiles, _i(off),
+                                                    C.c_void_p(all_edges_ptr or 0), n_edges))
 
     def set_option(self, key, value):
         self._chk(self.L.trg_engine_set_option(self.h, str(key).encode(), str(value).encode()))
