@@ -37,35 +37,71 @@ MOUNTAIN = dict(expand_dist=0.6, robot_size=0.3, height_threshold=0.16, collisio
                 update_collision_threshold=0.5, safety_factor=3.0, goal_tolerance=0.8)
 
 
-def cpu_baseline(sample_num, seconds_hint=20.0):
+def _host_cpu():
+    model, cores = "unknown", os.cpu_count() or 0
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, cores
+
+
+def cpu_baseline(sample_num, reps=3):
     """The CPU oracle (oracle/, a port of the reference algorithm; its spatial queries run through
-    the reference kdtree.c when oracle/_ref is present) timed on this box's host, one core, on a
-    bounded tile of the same terrain generator / parameters."""
+    the reference kdtree.c when oracle/_ref is present) timed on this box's host, one core (pinned),
+    on a bounded tile of the same terrain generator / parameters: `reps` repetitions, median."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_api as oa
     from trg_planner import synth
-    nx = ny = 1200  # 1.44 M points, ~94 k nodes at S=16: about 10-25 s of single-core work
+    try:  # one core, like the reference's hot path (single thread under TRG::mtx.graph)
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+        pinned = True
+    except (AttributeError, OSError):
+        pinned = False
+    nx = ny = 1200  # 1.44 M points, ~94 k nodes at S=16: about 7 s of single-core work per repetition
     cloud = synth.mountain_cloud(nx, ny, seed=20250418)
     used_ref = oa.use_reference_kd(True)
     prm = dict(MOUNTAIN, sample_num=sample_num)
-    o = oa.Oracle(**prm)
-    o.set_sampler(7, 0, 16)
-    t0 = time.perf_counter()
-    o.set_global_map(cloud)
-    t1 = time.perf_counter()
-    ok = o.init_graph([nx * 0.05, ny * 0.05, 0.0])
-    t2 = time.perf_counter()
-    g = o.graph(0)
-    c = o.counters()
+    runs = []
+    for _ in range(reps):
+        o = oa.Oracle(**prm)
+        o.set_sampler(7, 0, 16)
+        t0 = time.perf_counter()
+        o.set_global_map(cloud)
+        t1 = time.perf_counter()
+        ok = o.init_graph([nx * 0.05, ny * 0.05, 0.0])
+        t2 = time.perf_counter()
+        g = o.graph(0)
+        c = o.counters()
+        runs.append(((g.V + g.E) / (t2 - t0), t1 - t0, t2 - t1, g.V, g.E, bool(ok), c["expanded"]))
+        o.close()
     oa.use_reference_kd(False)
-    items = g.V + g.E
+    runs.sort()
+    val, t_index, t_graph, V, E, ok, expanded = runs[len(runs) // 2]
+    model, ncpu = _host_cpu()
+    full = None
+    fpath = os.path.join(ROOT, "profiles", "r02_fullscale_parity_c3.json")
+    if os.path.exists(fpath):  # the oracle on the FULL C3 cloud, kept record of the parity run
+        fj = json.load(open(fpath))
+        full = {"index_s": fj["oracle_index_s"], "init_graph_s": fj["oracle_init_graph_s"],
+                "nodes+edges/s": (fj["V_oracle"] + fj["E_oracle"]) /
+                                 (fj["oracle_index_s"] + fj["oracle_init_graph_s"]),
+                "source": os.path.relpath(fpath, ROOT)}
     return {
-        "value": items / (t2 - t0), "unit": "nodes+edges/s", "cores": 1, "kind": "port",
-        "sample": (f"{nx}x{ny}={nx * ny} pt tile of the same generator/params (S={sample_num}), "
-                   f"V'={g.V} E'={g.E}, index {t1 - t0:.2f}s + initGraph {t2 - t1:.2f}s; "
-                   f"TRG logic = oracle/trg_oracle.cpp (port), kd-tree = "
-                   f"{'reference kdtree.c (oracle/_ref)' if used_ref else 'oracle/okd.c restatement'}"),
-        "ok": bool(ok), "us_per_expanded_node": 1e6 * (t2 - t1) / max(1, c["expanded"]),
+        "value": val, "unit": "nodes+edges/s", "cores": 1, "kind": "port",
+        "sample": (f"bounded sample: {nx}x{ny}={nx * ny} pt tile of the same generator/params "
+                   f"(S={sample_num}), V'={V} E'={E}; median of {reps} repetitions "
+                   f"(index {t_index:.2f}s + initGraph {t_graph:.2f}s); TRG logic = oracle/trg_oracle.cpp "
+                   f"(port), kd-tree = "
+                   f"{'reference kdtree.c (oracle/_ref)' if used_ref else 'oracle/okd.c restatement'}; "
+                   f"{'pinned to one core' if pinned else 'not pinned'}"),
+        "host_cpu": model, "host_logical_cpus": ncpu,
+        "all_repetitions": [r[0] for r in runs],
+        "full_c3_cloud_record": full,
+        "ok": ok, "us_per_expanded_node": 1e6 * t_graph / max(1, expanded),
     }
 
 
@@ -123,26 +159,24 @@ def main():
     eng.set_sampler(7, 16)
     if world > 1:
         eng.set_tile(core, epoch=rank)
-    stitch_info = {"cross_edges": 0, "boundary_records": 0}
+    stitch_info = {"cross_edges": 0, "boundary_records": 0, "backend": "none"}
 
     def step():
         eng.set_global_map_device(d_cloud.data_ptr(), n_pts, 3)
         eng.init_graph(start)
-        V, E = eng.graph_sizes("global")
-        if world > 1:
-            class _G:  # node positions only: the stitch needs nothing else of the tile graph
-                pass
-            g = _G()
-            g.xyz = eng.node_xyz("global")
-            t_st = time.perf_counter()
-            (ids, _, _), nrec = tiled.stitch(rank, g, core, cols, rows, MOUNTAIN["expand_dist"],
-                                             eng.edge_risk, dist, coll_dev)
-            mine = int(((ids[:, 0] == rank).sum() + (ids[:, 2] == rank).sum())) if ids.size else 0
-            stitch_info["cross_edges"] = int(ids.shape[0])
-            stitch_info["boundary_records"] = nrec
-            stitch_info["ms_stitch_last"] = 1e3 * (time.perf_counter() - t_st)
-            E += mine  # directed cross edges that end up in this tile's adjacency lists
-        return V, E
+        if world == 1:
+            return eng.graph_sizes("global")
+        # boundary extraction, pair search, cross-edge evaluation and the assembly of this tile's rows
+        # of the global graph run on the GPU (trg_engine_stitch_*); the two all-gather-v exchanges
+        # carry device tensors over RCCL (host tensors over gloo in the more-ranks-than-GPUs rehearsal)
+        t_st = time.perf_counter()
+        info = tiled.stitch_device(eng, rank, core, cols, rows, dist,
+                                   None if coll_dev.type == "cuda" else coll_dev)
+        stitch_info["cross_edges"] = info["n_cross"]
+        stitch_info["boundary_records"] = info["n_boundary"]
+        stitch_info["backend"] = info["backend"]
+        stitch_info["ms_stitch_last"] = 1e3 * (time.perf_counter() - t_st)
+        return eng.graph_sizes("stitched")  # this rank's rows of the assembled global graph
 
     def fence():
         torch.cuda.synchronize()
@@ -172,32 +206,51 @@ def main():
                          f"levels={st_dbg['bfs_levels']} reason={eng.fallback_reason!r}\n")
     if world > 1:
         items, dt = tiling.reduce_throughput(items, dt, dist, coll_dev)
+        # nodes / directed edges of the assembled global graph = the sum of the ranks' stitched rows
+        ve = torch.tensor([float(V), float(E)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ve, op=dist.ReduceOp.SUM)
+        V, E = int(ve[0].item()), int(ve[1].item())
 
     if rank == 0:
         st = eng.stats()
-        # the three map-query kernels (the rest of the build is index/graph bookkeeping); names are
-        # those rocprofv3 shows for the path that ran
+        # the map-query kernels (the rest of the build is index/graph bookkeeping); names are those
+        # rocprofv3 shows for the path that ran.  Device BFS: k_level_sample holds the sampling discs
+        # (+ the elevation lookups), k_level_spec the speculative parent edges (timed together inside
+        # the level loop: ms_sample_kernel), k_calls_gather the deferred wireEdge evaluations.
         dev = st["used_device_bfs"] == 1
-        kernels = {
-            ("k_calls_gather" if dev else "k_edges"):
-                (acc["bytes_edge_kernel"], acc["ms_edge_kernel"], acc["launches_edge_kernel"]),
-            ("k_bfs_spec" if dev else "k_spec_edges"):
-                (acc["bytes_spec_kernel"], acc["ms_spec_kernel"], acc["launches_spec_kernel"]),
-            "k_sample_nodes": (acc["bytes_sample_kernel"], acc["ms_sample_kernel"],
-                               acc["launches_sample_kernel"]),
-        }
+        if dev:
+            kernels = {
+                "k_calls_gather": (acc["bytes_edge_kernel"], acc["ms_edge_kernel"], acc["launches_edge_kernel"]),
+                "k_level_sample+k_level_spec": (acc["bytes_sample_kernel"] + acc["bytes_spec_kernel"],
+                                                acc["ms_sample_kernel"], acc["launches_sample_kernel"]),
+            }
+        else:
+            kernels = {
+                "k_edges": (acc["bytes_edge_kernel"], acc["ms_edge_kernel"], acc["launches_edge_kernel"]),
+                "k_spec_edges": (acc["bytes_spec_kernel"], acc["ms_spec_kernel"], acc["launches_spec_kernel"]),
+                "k_sample_nodes": (acc["bytes_sample_kernel"], acc["ms_sample_kernel"],
+                                   acc["launches_sample_kernel"]),
+            }
         dom = max(kernels, key=lambda k: kernels[k][1])
         b, ms, launches = kernels[dom]
         achieved = (b / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        # whole build: SURVEY section 8(d) B_alg = B_index + B_query + B_out over T_build
+        b_out = 16 * V + 4 * (V + 1) + 12 * E
+        b_alg_step = (acc["bytes_index_build"] + acc["bytes_sample_kernel"] + acc["bytes_spec_kernel"] +
+                      acc["bytes_edge_kernel"]) / max(1, args.steps) + b_out
+        build_gbps = (b_alg_step / 1e9) / (dt / max(1, args.steps))
         # HBM bytes per launch from the separate rocprofv3 --pmc passes of the same workload
-        # (profiles/, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        # (profiles/, scripts/profile_gpu.sh; FETCH_SIZE factor as established by scripts/fetch_unit.sh)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", f"r01_{args.workload}_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if dom in tj:
-                traffic = tj[dom]["hbm_bytes_per_dispatch"]
-                traffic_src = os.path.relpath(tpath, ROOT)
+        for tag in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", f"{tag}_{args.workload}_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                key = dom if dom in tj else dom.split("+")[0]
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_dispatch"]
+                    traffic_src = os.path.relpath(tpath, ROOT)
+                    break
         out = {
             "metric": "TRG nodes+edges built/sec", "value": items / dt, "unit": "nodes+edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,15 +260,19 @@ def main():
                 "workload": label, "points_per_gpu": n_pts, "V_prime": V, "E_prime": E,
                 "sampler": "counter-based table, seed 7, 16 bits",
                 "sharding": (f"{cols}x{rows} tiles of one continuous terrain, one per rank, core + "
-                             f"1.1 m halo; boundary edges stitched by 2 all-gather-v over RCCL "
+                             f"1.1 m halo; boundary edges stitched on the GPUs, 2 all-gather-v over "
+                             f"{ {'nccl': 'RCCL (device tensors)', 'gloo': 'gloo (host tensors: rehearsal)'}.get(stitch_info['backend'], stitch_info['backend'])} "
                              f"({stitch_info['cross_edges']} cross edges, "
-                             f"{stitch_info['boundary_records']} boundary records)")
+                             f"{stitch_info['boundary_records']} boundary records); V'/E' = the assembled "
+                             f"global graph")
                 if world > 1 else "single tile",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": traffic_src,
+                "build_GBps": build_gbps, "build_frac": build_gbps / HBM_PEAK_GBPS,
+                "build_alg_bytes_per_step": b_alg_step,
                 "alg_bytes_per_launch": b / max(1, launches),
                 "avg_launch_ms": ms / max(1, launches), "launches": launches,
                 "all_kernels_GBps": {k: ((v[0] / 1e9) / (v[1] / 1e3) if v[1] > 0 else 0.0)

@@ -3,6 +3,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (first: a process that uses torch's HIP runtime next to the engine must load
+#                torch's bundled ROCm libraries before libtrg_engine.so pulls in the system ones)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "trg-planner_amd"))

@@ -76,8 +76,12 @@ def _stitch_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     # ragged all-gather: rank r contributes r+2 rows (and rank 1 an empty second array)
     a = np.arange((rank + 2) * 3, dtype=np.float32).reshape(rank + 2, 3) + 100 * rank
-    got = tiled.allgatherv(a, dist)
-    empty = tiled.allgatherv(np.zeros((0 if rank == 1 else 2, 4), np.int32), dist)
+    cat, counts = tiled.allgatherv_t(torch.from_numpy(a), dist)
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    got = [cat.numpy()[bounds[k]:bounds[k + 1]] for k in range(world)]
+    ecat, ecounts = tiled.allgatherv_t(torch.zeros((0 if rank == 1 else 2, 4), dtype=torch.int32), dist)
+    empty = [np.zeros((c, 4), np.int32) for c in ecounts]
+    assert ecat.shape == (sum(ecounts), 4)
     # a two-tile seam: nodes on a line at y = 1, tile 0 left of x = 5, tile 1 right of it
     class G:  # minimal tile graph
         pass
@@ -90,7 +94,7 @@ def _stitch_worker(rank, world, port, q):
         d = np.sqrt((p1[:, 0] - p2[:, 0]) ** 2 + (p1[:, 1] - p2[:, 1]) ** 2).astype(np.float32)
         return np.zeros(len(p1), np.int32), np.full(len(p1), 9, np.int32), 0.1 + 0 * d, d
 
-    (ids, w, d), nrec = tiled.stitch(rank, g, core, 2, 1, 0.6, fake_edge_risk, dist)
+    (ids, w, d), nrec = tiled.stitch_host(rank, g, core, 2, 1, 0.6, fake_edge_risk, dist)
     q.put((rank, [x.tolist() for x in got], [x.shape for x in empty], ids.tolist(), d.tolist(), nrec))
     dist.barrier()
     dist.destroy_process_group()

@@ -32,13 +32,10 @@ def test_tiled_build_matches_tiled_oracle(oa, synth, layout):
         assert e.stats()["used_device_bfs"] == 1, e.fallback_reason
         engines.append(e)
         graphs.append(e.graph("global"))
-    all_idx = [tiled.boundary_nodes(g.xyz, cores[t], cols, rows, t, prm["expand_dist"])
-               for t, g in enumerate(graphs)]
-    all_xyz = [np.ascontiguousarray(g.xyz[i], np.float32) for g, i in zip(graphs, all_idx)]
-    parts = [tiled.stitch_local(t, all_idx, all_xyz, prm["expand_dist"], e.edge_risk)
-             for t, e in enumerate(engines)]
-    stitched = tuple(np.concatenate([p[k] for p in parts], 0) for k in range(3))
-    G = tiled.assemble_global(graphs, stitched)
+    # the native stitch (trg_engine_stitch_*: boundary, cross, assemble on the GPU), ranks emulated
+    parts, cross = tiled.stitch_emulated(engines, cores, cols, rows)
+    G = tiled.concat_stitched(parts)
+    stitched = (cross[:, :4],)
 
     o_graphs, o_stitched, OG = tiled_oracle.build_tiled_oracle(
         oa, synth, tiled, prm, cols, rows, nx, ny, halo, seed, sseed, terrain)
@@ -49,7 +46,8 @@ def test_tiled_build_matches_tiled_oracle(oa, synth, layout):
                 (g.xyz[:, 1] < c[3])).all()
         assert g.V == og.V and np.array_equal(g.col, og.col) and np.array_equal(g.xyz, og.xyz)
     assert stitched[0].shape[0] > 10                      # the seam really got edges
-    assert np.array_equal(stitched[0], o_stitched[0])
+    assert np.array_equal(stitched[0], o_stitched[0])           # same cross edges in the same order
+    assert np.array_equal(np.concatenate([p.cid for p in parts]), np.arange(G["V"]))  # rows = global ids
     assert G["V"] == OG["V"] and np.array_equal(G["rowptr"], OG["rowptr"])
     assert np.array_equal(G["col"], OG["col"]) and np.array_equal(G["state"], OG["state"])
     assert np.array_equal(G["xyz"].view(np.uint32), OG["xyz"].view(np.uint32))
@@ -65,14 +63,8 @@ def test_tiled_build_matches_tiled_oracle(oa, synth, layout):
 
 
 def _stitch_engines(tiled, prm, cols, rows, cores, engines):
-    graphs = [e.graph("global") for e in engines]
-    all_idx = [tiled.boundary_nodes(g.xyz, cores[t], cols, rows, t, prm["expand_dist"])
-               for t, g in enumerate(graphs)]
-    all_xyz = [np.ascontiguousarray(g.xyz[i], np.float32) for g, i in zip(graphs, all_idx)]
-    parts = [tiled.stitch_local(t, all_idx, all_xyz, prm["expand_dist"], e.edge_risk)
-             for t, e in enumerate(engines)]
-    stitched = tuple(np.concatenate([p[k] for p in parts], 0) for k in range(3))
-    return graphs, stitched, tiled.assemble_global(graphs, stitched)
+    parts, cross = tiled.stitch_emulated(engines, cores, cols, rows)
+    return parts, cross, tiled.concat_stitched(parts)
 
 
 def _assert_global_equal(G, OG):

@@ -9,16 +9,25 @@ tiled build is defined as follows (the CPU oracle implements the same rule, test
    one change: a sample outside core_t counts as a rejected draw, so every node of tile t lies in
    core_t.  Sampler: same seed, epoch = tile index.  cleanGraph runs per tile.
 2. Boundary nodes = nodes closer than expand_dist to a core border shared with another tile.
-   Every rank publishes them (all-gather-v: tile, local id, x, y, z).
+   Every rank publishes them (all-gather-v: local id, x, y, z).
 3. For every pair (a in tile t, b in tile u, t < u) with ||a - b|| < expand_dist (fp32 norm as
    trg.cpp:414) rank t evaluates wireEdge's position-only part for (a, b) on its own map; the
    successful ones are published (second all-gather-v).
 4. Every node appends its cross edges after its tile-local edges, ordered by the global id of the
    other endpoint.  Global id = tile offset (exclusive prefix of tile node counts) + local id.
+
+Product path: stitch_device (the engine's native trg_engine_stitch_* steps on the GPU, device tensors
+through the two exchanges).  The numpy functions below state the same rule a second time for the
+tiled CPU oracle and the CPU gloo test.
 """
 from __future__ import annotations
 
 import numpy as np
+
+try:  # the exchanges ride on torch.distributed; torch's ROCm libraries must load before the engine's
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
 
 
 def tile_cores(cols, rows, nx, ny, spacing=0.1):
@@ -59,68 +68,98 @@ def boundary_nodes(xyz, core, cols, rows, tile, dist):
     return np.nonzero(m)[0].astype(np.int32)
 
 
-def allgatherv(arr, dist=None, device=None):
-    """All-gather of per-rank arrays with different leading sizes (RCCL has no native allgatherv:
-    counts first, then padded payloads).  Returns the list of every rank's array."""
-    arr = np.ascontiguousarray(arr)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return [arr]
+def allgatherv_t(t, dist=None):
+    """All-gather of per-rank torch tensors with different leading sizes ON THE DEVICE THEY LIVE ON
+    (device tensors over RCCL, host tensors over gloo): counts first, then padded payloads (RCCL has
+    no native allgatherv).  Returns (concatenation in rank order, counts list)."""
     import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return t, [int(t.shape[0])]
     world = dist.get_world_size()
-    dev = device if device is not None else torch.device("cpu")
-    n = torch.tensor([arr.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
     dist.all_gather(counts, n)
-    counts = torch.cat(counts).cpu().tolist()  # one device round trip for all counts
-    width = int(np.prod(arr.shape[1:])) if arr.ndim > 1 else 1
+    counts = torch.cat(counts).cpu().tolist()  # the one host round trip of the exchange
     pad = max(max(counts), 1)
-    tdtype = torch.from_numpy(np.zeros(1, arr.dtype)).dtype
-    buf = torch.zeros((pad, width), dtype=tdtype, device=dev)
-    if arr.shape[0]:
-        buf[:arr.shape[0]] = torch.from_numpy(arr.reshape(arr.shape[0], width)).to(dev)
-    outs = [torch.zeros_like(buf) for _ in range(world)]
+    buf = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    buf[:t.shape[0]] = t
+    outs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
-    host = torch.stack(outs).cpu().numpy()  # one copy back for all ranks' payloads
-    return [host[k, :c].reshape((c,) + arr.shape[1:]) for k, c in enumerate(counts)]
+    return torch.cat([o[:c] for o, c in zip(outs, counts)], 0), counts
 
 
+def stitch_device(eng, my_tile, core, cols, rows, dist=None, gather_dev=None):
+    """Steps 2-4 for one rank (rank == tile) with the engine's native stitch (include/trg_engine.h,
+    trg_engine_stitch_*): boundary extraction, pair search, cross-edge evaluation and the assembly of
+    this tile's rows of the global graph run on the GPU; the two all-gather-v exchanges carry device
+    tensors (RCCL) -- or host tensors when `gather_dev` is the CPU (gloo rehearsal).
+    Returns dict(n_boundary, n_cross, node_offsets, backend)."""
+    import torch
+    ntiles = cols * rows
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gdev = dev if gather_dev is None else gather_dev
+    nb = eng.stitch_boundary(core, cols, rows, my_tile)
+    rec = torch.empty((max(nb, 1), 4), dtype=torch.int32, device=dev)
+    if nb:
+        eng.stitch_boundary(core, cols, rows, my_tile, rec.data_ptr(), nb)
+    all_rec, counts = allgatherv_t(rec[:nb].to(gdev), dist)
+    all_rec = all_rec.to(dev).contiguous()
+    rec_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    # exchange of the tiles' node counts rides on the same collective shape (one int per rank)
+    V = eng.graph_sizes("global")[0]
+    vt, _ = allgatherv_t(torch.tensor([[V]], dtype=torch.int32, device=gdev), dist)
+    node_off = np.concatenate([[0], np.cumsum(vt.cpu().numpy().reshape(-1))]).astype(np.int32)
+    if len(counts) != ntiles:  # single process: nothing to stitch against
+        eng.stitch_assemble(0, 1, node_off[:2], None, 0)
+        return dict(n_boundary=0, n_cross=0, node_offsets=node_off, backend="none")
+    torch.cuda.synchronize()
+    nc = eng.stitch_cross(my_tile, ntiles, all_rec.data_ptr(), rec_off)
+    edges = torch.empty((max(nc, 1), 6), dtype=torch.int32, device=dev)
+    if nc:
+        nc = eng.stitch_cross(my_tile, ntiles, all_rec.data_ptr(), rec_off, edges.data_ptr(), nc)
+    all_edges, ecounts = allgatherv_t(edges[:nc].to(gdev), dist)
+    all_edges = all_edges.to(dev).contiguous()
+    torch.cuda.synchronize()
+    eng.stitch_assemble(my_tile, ntiles, node_off, all_edges.data_ptr(), int(all_edges.shape[0]))
+    return dict(n_boundary=int(rec_off[-1]), n_cross=int(all_edges.shape[0]), node_offsets=node_off,
+                backend=(dist.get_backend() if dist is not None and dist.is_initialized() else "none"))
+
+
+def concat_stitched(parts):
+    """Global CSR from the tiles' stitched rows (objects with rowptr, col, w, dist, xyz, state in tile
+    order) -- a concatenation: the rows already carry global column ids."""
+    rowptr = [np.zeros(1, np.int64)]
+    base = 0
+    for g in parts:
+        rowptr.append(g.rowptr[1:].astype(np.int64) + base)
+        base += int(g.rowptr[-1])
+    sizes = [g.V for g in parts]
+    return dict(V=int(sum(sizes)), xyz=np.concatenate([g.xyz for g in parts], 0),
+                state=np.concatenate([g.state for g in parts], 0), rowptr=np.concatenate(rowptr),
+                col=np.concatenate([g.col for g in parts]).astype(np.int64),
+                w=np.concatenate([g.w for g in parts]), dist=np.concatenate([g.dist for g in parts]),
+                offsets=np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64))
+
+
+# ---- reference implementation of the stitch rule in numpy (tests/tiled_oracle.py drives the CPU
+# oracle through it; the product path is stitch_device above) ------------------------------------------
 def cross_pairs(my_tile, records_per_tile, expand_dist):
     """Pairs (index into my boundary list, other tile, index into its boundary list) with my tile
-    as the LOWER tile and fp32 planar distance < expand_dist, as three int arrays ordered by
-    (other tile, my index, its index).  records: float32 (k, 3) xyz.
-    A kd-tree prefilter (fp64, slightly enlarged radius) finds the candidates, the decision is the
-    reference's fp32 expression (existing - sample).norm() < d, trg.cpp:414."""
-    from scipy.spatial import cKDTree
+    as the LOWER tile and fp32 planar distance < expand_dist -- the reference's expression
+    (existing - sample).norm() < d, trg.cpp:414 -- ordered by (other tile, my index, its index)."""
     mine = records_per_tile[my_tile]
     d = np.float32(expand_dist)
     out_a, out_u, out_b = [], [], []
-    if mine.shape[0]:
-        lo, hi = mine[:, :2].min(0) - 1.01 * d, mine[:, :2].max(0) + 1.01 * d
-        my_tree = None
-        for u in range(my_tile + 1, len(records_per_tile)):
-            other = records_per_tile[u]
-            if other.shape[0] == 0:
-                continue
-            o_lo, o_hi = other[:, :2].min(0), other[:, :2].max(0)
-            if (o_lo > hi).any() or (o_hi < lo).any():
-                continue  # bounding boxes farther apart than expand_dist: no pair possible
-            if my_tree is None:
-                my_tree = cKDTree(mine[:, :2].astype(np.float64))
-            pairs = my_tree.sparse_distance_matrix(cKDTree(other[:, :2].astype(np.float64)),
-                                                   float(expand_dist) * 1.001 + 1e-6,
-                                                   output_type="coo_matrix")
-            ia, ib = pairs.row.astype(np.int64), pairs.col.astype(np.int64)
-            if ia.size == 0:
-                continue
-            dx = mine[ia, 0] - other[ib, 0]
-            dy = mine[ia, 1] - other[ib, 1]
-            dist = np.sqrt(dx * dx + dy * dy, dtype=np.float32)  # fp32, no FMA
-            keep = dist < d
-            ia, ib = ia[keep], ib[keep]
-            order = np.lexsort((ib, ia))
-            out_a.append(ia[order])
-            out_u.append(np.full(order.size, u, np.int64))
-            out_b.append(ib[order])
+    for u in range(my_tile + 1, len(records_per_tile)):
+        other = records_per_tile[u]
+        if mine.shape[0] == 0 or other.shape[0] == 0:
+            continue
+        dx = mine[:, None, 0] - other[None, :, 0]
+        dy = mine[:, None, 1] - other[None, :, 1]
+        ia, ib = np.nonzero(np.sqrt(dx * dx + dy * dy, dtype=np.float32) < d)  # fp32, no FMA; row-major
+        out_a.append(ia.astype(np.int64))
+        out_u.append(np.full(ia.size, u, np.int64))
+        out_b.append(ib.astype(np.int64))
     if not out_a:
         z = np.zeros(0, np.int64)
         return z, z, z
@@ -129,35 +168,35 @@ def cross_pairs(my_tile, records_per_tile, expand_dist):
 
 def assemble_global(tile_graphs, stitched):
     """Global CSR from the tile graphs (objects with V, rowptr, col, w, dist, xyz, state) and the
-    stitched cross edges (array rows: tile_a, lid_a, tile_b, lid_b; parallel arrays w, dist)."""
+    stitched cross edges (array rows: tile_a, lid_a, tile_b, lid_b; parallel arrays w, dist): every
+    node's cross edges follow its tile-local edges, ordered by the other end's global id."""
     sizes = [g.V for g in tile_graphs]
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     V = int(offs[-1])
     ids, w, dist = stitched
-    extra = [[] for _ in range(V)]
-    for k in range(ids.shape[0]):
-        ga = int(offs[ids[k, 0]] + ids[k, 1])
-        gb = int(offs[ids[k, 2]] + ids[k, 3])
-        extra[ga].append((gb, float(w[k]), float(dist[k])))
-        extra[gb].append((ga, float(w[k]), float(dist[k])))
-    rowptr = [0]
-    col, ww, dd = [], [], []
     xyz = np.concatenate([g.xyz for g in tile_graphs], 0) if V else np.zeros((0, 3), np.float32)
     state = np.concatenate([g.state for g in tile_graphs], 0) if V else np.zeros(0, np.int32)
-    for t, g in enumerate(tile_graphs):
-        for i in range(g.V):
-            a, b = int(g.rowptr[i]), int(g.rowptr[i + 1])
-            col.extend((g.col[a:b].astype(np.int64) + offs[t]).tolist())
-            ww.extend(g.w[a:b].tolist())
-            dd.extend(g.dist[a:b].tolist())
-            for (gb, w_, d_) in sorted(extra[int(offs[t]) + i]):
-                col.append(gb)
-                ww.append(w_)
-                dd.append(d_)
-            rowptr.append(len(col))
-    return dict(V=V, xyz=xyz, state=state, rowptr=np.array(rowptr, np.int64),
-                col=np.array(col, np.int64), w=np.array(ww, np.float32),
-                dist=np.array(dd, np.float32), offsets=offs)
+    # local edges: (row, rank inside the row, col, w, dist)
+    rows_l = np.concatenate([np.repeat(np.arange(g.V, dtype=np.int64), np.diff(g.rowptr)) + offs[t]
+                             for t, g in enumerate(tile_graphs)]) if V else np.zeros(0, np.int64)
+    col_l = np.concatenate([g.col.astype(np.int64) + offs[t] for t, g in enumerate(tile_graphs)])
+    w_l = np.concatenate([g.w for g in tile_graphs])
+    d_l = np.concatenate([g.dist for g in tile_graphs])
+    ga = offs[ids[:, 0]] + ids[:, 1] if ids.shape[0] else np.zeros(0, np.int64)
+    gb = offs[ids[:, 2]] + ids[:, 3] if ids.shape[0] else np.zeros(0, np.int64)
+    rows_x = np.concatenate([ga, gb])
+    col_x = np.concatenate([gb, ga])
+    w_x = np.concatenate([w, w]).astype(np.float32)
+    d_x = np.concatenate([dist, dist]).astype(np.float32)
+    ox = np.lexsort((col_x, rows_x))  # a row's cross edges by the other end's global id
+    rows_all = np.concatenate([rows_l, rows_x[ox]])
+    kind = np.concatenate([np.zeros(rows_l.size, np.int8), np.ones(ox.size, np.int8)])
+    order = np.lexsort((np.arange(rows_all.size), kind, rows_all))  # stable: local first, then cross
+    deg = np.bincount(rows_all, minlength=V)
+    return dict(V=V, xyz=xyz, state=state, rowptr=np.concatenate([[0], np.cumsum(deg)]).astype(np.int64),
+                col=np.concatenate([col_l, col_x[ox]])[order],
+                w=np.concatenate([w_l, w_x[ox]])[order].astype(np.float32),
+                dist=np.concatenate([d_l, d_x[ox]])[order].astype(np.float32), offsets=offs)
 
 
 def stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk):
@@ -180,29 +219,68 @@ def stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk):
     return ids, w[ok].astype(np.float32), d[ok].astype(np.float32)
 
 
-def stitch(my_tile, graph, core, cols, rows, expand_dist, edge_risk, dist=None, device=None):
-    """Steps 2-3 for one rank (rank == tile).  `edge_risk(p1, p2) -> (status, n_pts, w, dist)`
-    evaluates wireEdge's position-only part on this rank's map (the engine's edge_risk_batch).
-    Returns (ids[k,4] int32, w[k], dist[k]) of ALL ranks' stitched edges, identical on every rank,
-    and the number of boundary records exchanged."""
+
+
+def stitch_host(my_tile, graph, core, cols, rows, expand_dist, edge_risk, dist=None):
+    """The stitch rule with numpy on the host (steps 2-3; what tests/tiled_oracle.py and the CPU
+    world_size-2 gloo test run; the product path is stitch_device): `edge_risk(p1, p2) -> (status,
+    n_pts, w, dist)` evaluates wireEdge's position-only part on this rank's map.  Returns
+    (ids[k,4] int32, w[k], dist[k]) of ALL ranks' cross edges, identical on every rank, and the number
+    of boundary records exchanged."""
+    import torch
     bidx = boundary_nodes(graph.xyz, core, cols, rows, my_tile, expand_dist)
-    # exchange 1: boundary records (local id, x, y, z), 16 bytes each, one all-gather-v
-    # (carried as int32 words: the payload is only ever copied, never computed on)
-    rec = np.empty((bidx.shape[0], 4), np.int32)
+    rec = np.empty((bidx.shape[0], 4), np.int32)  # (local id, x, y, z) as int32 words: only ever copied
     rec[:, 0] = bidx
     rec[:, 1:] = np.ascontiguousarray(graph.xyz[bidx], dtype=np.float32).view(np.int32)
-    all_rec = allgatherv(rec, dist, device)
-    if len(all_rec) == 1:  # single process: nothing to stitch against
+    all_rec, counts = allgatherv_t(torch.from_numpy(rec), dist)
+    if len(counts) == 1:  # single process: nothing to stitch against
         z = np.zeros(0, np.float32)
         return (np.zeros((0, 4), np.int32), z, z), 0
-    all_idx = [np.ascontiguousarray(r[:, 0]) for r in all_rec]
-    all_xyz = [np.ascontiguousarray(r[:, 1:]).view(np.float32) for r in all_rec]
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    all_rec = all_rec.numpy()
+    per = [all_rec[bounds[k]:bounds[k + 1]] for k in range(len(counts))]
+    all_idx = [np.ascontiguousarray(r[:, 0]) for r in per]
+    all_xyz = [np.ascontiguousarray(r[:, 1:]).view(np.float32) for r in per]
     ids, w, d = stitch_local(my_tile, all_idx, all_xyz, expand_dist, edge_risk)
-    # exchange 2: the cross edges this tile owns (tile_a, id_a, tile_b, id_b, weight, dist), 24 bytes
-    out = np.empty((ids.shape[0], 6), np.int32)
+    out = np.empty((ids.shape[0], 6), np.int32)  # (tile_a, id_a, tile_b, id_b, weight, dist), 24 bytes
     out[:, :4] = ids
     out[:, 4] = np.ascontiguousarray(w, dtype=np.float32).view(np.int32)
     out[:, 5] = np.ascontiguousarray(d, dtype=np.float32).view(np.int32)
-    g = np.concatenate(allgatherv(out, dist, device), 0)
+    g, _ = allgatherv_t(torch.from_numpy(out), dist)
+    g = g.numpy()
     return (np.ascontiguousarray(g[:, :4]), np.ascontiguousarray(g[:, 4]).view(np.float32),
-            np.ascontiguousarray(g[:, 5]).view(np.float32)), int(sum(a.shape[0] for a in all_idx))
+            np.ascontiguousarray(g[:, 5]).view(np.float32)), int(bounds[-1])
+
+
+def stitch_emulated(engines, cores, cols, rows):
+    """All ranks of a tiling one after the other on ONE GPU (tests, rehearsals): the same three
+    native steps as stitch_device, the two exchanges replaced by concatenations.  Returns the list of
+    every tile's stitched graph (rows with global column ids) and the number of cross edges."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ntiles = cols * rows
+    recs = []
+    for t, e in enumerate(engines):
+        nb = e.stitch_boundary(cores[t], cols, rows, t)
+        r = torch.empty((max(nb, 1), 4), dtype=torch.int32, device=dev)
+        if nb:
+            e.stitch_boundary(cores[t], cols, rows, t, r.data_ptr(), nb)
+        recs.append(r[:nb])
+    all_rec = torch.cat(recs, 0).contiguous()
+    rec_off = np.concatenate([[0], np.cumsum([int(r.shape[0]) for r in recs])]).astype(np.int32)
+    node_off = np.concatenate([[0], np.cumsum([e.graph_sizes("global")[0] for e in engines])]).astype(np.int32)
+    torch.cuda.synchronize()
+    parts = []
+    for t, e in enumerate(engines):
+        nc = e.stitch_cross(t, ntiles, all_rec.data_ptr(), rec_off)
+        ed = torch.empty((max(nc, 1), 6), dtype=torch.int32, device=dev)
+        if nc:
+            nc = e.stitch_cross(t, ntiles, all_rec.data_ptr(), rec_off, ed.data_ptr(), nc)
+        parts.append(ed[:nc])
+    all_edges = torch.cat(parts, 0).contiguous()
+    torch.cuda.synchronize()
+    out = []
+    for t, e in enumerate(engines):
+        e.stitch_assemble(t, ntiles, node_off, all_edges.data_ptr(), int(all_edges.shape[0]))
+        out.append(e.graph("stitched"))
+    return out, all_edges.cpu().numpy()
