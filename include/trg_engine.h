@@ -113,14 +113,15 @@ typedef struct TrgStats {
   uint64_t gate_uncertain;     /* slope gates decided by host libm atan2f */
   uint64_t sync_batches;       /* synchronous GPU round trips forced by the replay */
   /* bytes of map points inside query radii that the GPU kernels touched (12 B per hit) */
-  uint64_t bytes_sample_kernel;   /* k_sample_nodes */
-  uint64_t bytes_spec_kernel;     /* k_spec_edges (speculative parent edges) */
-  uint64_t bytes_edge_kernel;     /* k_edges (deferred wireEdge evaluations) */
+  uint64_t bytes_sample_kernel;   /* sampling discs: k_level_sample (device BFS) / k_sample_nodes */
+  uint64_t bytes_spec_kernel;     /* speculative parent edges: k_level_spec / k_spec_edges */
+  uint64_t bytes_edge_kernel;     /* deferred wireEdge evaluations: k_calls_gather / k_edges */
   uint64_t bytes_index_build;
   /* device time per kernel, milliseconds, measured with hipEvents on the launch stream.  Inside the
-   * device-resident BFS the sampling and speculative-edge kernels are timed on every 8th level
-   * only (an event pair costs ~12 us of stream time per level) and the sums are scaled by
-   * launches / timed launches; the deferred edge evaluations are timed in full. */
+   * device-resident BFS k_level_sample + k_level_spec are timed TOGETHER on every 8th level only (an
+   * event pair costs ~12 us of stream time per level), reported as ms_sample_kernel /
+   * launches_sample_kernel (ms_spec_kernel stays 0) and scaled by launches / timed launches; the
+   * deferred edge evaluations are timed in full. */
   double ms_index_build;
   double ms_sample_kernel;
   double ms_spec_kernel;
@@ -148,6 +149,10 @@ typedef struct TrgStats {
                                   in the reference's map-tree visiting order (kdtree.c:303-362) */
   uint64_t map_nn_unresolved;  /* ties left at "lowest cloud index" (more than 16 points tied, or more
                                   than 256 tied samples in one launch) -- 0 in practice */
+  uint64_t bytes_spec_created; /* device path: the part of bytes_spec_kernel spent on the parent edges of
+                                  the nodes that were created -- the wireEdge(node, new_node) calls the
+                                  reference itself evaluates (trg.cpp:425); the rest of
+                                  bytes_spec_kernel is speculation on candidates that merged */
 } TrgStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -183,6 +188,8 @@ TrgStatus trg_engine_update_graph(TrgEngine *e);
 /* ---- export ---------------------------------------------------------------------------------- */
 /* reference: TRG::getGraph / getGraphCopy trg.cpp:805-824 */
 TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out);
+/* node / directed-edge counts of a graph without touching (or, for TRG_KIND_STITCHED, fetching) its arrays */
+TrgStatus trg_engine_graph_sizes(TrgEngine *e, TrgKind kind, int32_t *num_nodes, int32_t *num_edges);
 /* reference: TRG::saveGraph / loadPrebuiltGraph trg.cpp:66-177 (same JSON schema) */
 TrgStatus trg_engine_save_json(TrgEngine *e, const char *path);
 TrgStatus trg_engine_load_json(TrgEngine *e, const char *path);

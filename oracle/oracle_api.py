@@ -19,7 +19,7 @@ COUNTER_NAMES = [
     "collision_queries", "collision_hits", "nn_map_queries", "ellipse_queries", "ellipse_hits",
     "wire_calls", "wire_evals", "wire_ok", "wire_gate", "wire_seg", "wire_empty", "wire_few",
     "wire_clamped", "expanded", "trials", "samples", "created", "invalid_created",
-    "nn_node_queries", "sample_hits",
+    "nn_node_queries", "sample_hits", "wire_hits_new", "wire_hits_other",
 ]
 
 
@@ -234,7 +234,7 @@ class Oracle:
         return dict(src=src, dst=dst, status=status, n_pts=n_pts, weight=w, dist=d)
 
     def counters(self):
-        out = (C.c_uint64 * 20)()
+        out = (C.c_uint64 * len(COUNTER_NAMES))()
         self.L.trg_oracle_counters(self.h, out)
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
 

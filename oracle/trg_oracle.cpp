@@ -381,6 +381,9 @@ struct OCounters {
   uint64_t expanded = 0, trials = 0, samples = 0, created = 0, invalid_created = 0;
   uint64_t nn_node_queries = 0;
   uint64_t sample_hits = 0;  // the part of collision_hits issued by expandGraph's sampling loop (trg.cpp:398)
+  // map points inside the queries (segment discs + ellipse gather) of wireEdge(node, new_node)
+  // (trg.cpp:425) and of every other wireEdge call
+  uint64_t wire_hits_new = 0, wire_hits_other = 0;
 };
 
 inline float norm2(float dx, float dy) { return std::sqrt(dx * dx + dy * dy); }
@@ -712,7 +715,9 @@ class Oracle {
     cnt_.wire_evals++;
     float weight, dist;
     int n_pts;
+    const uint64_t hits_before = cnt_.collision_hits + cnt_.ellipse_hits;
     int status = edgeRisk(node1->pos_, node2->pos_, type, weight, dist, n_pts);
+    cnt_.wire_hits_other += cnt_.collision_hits + cnt_.ellipse_hits - hits_before;
     if (trace_wires_) {
       wire_trace_.push_back(WireTrace{node1->cid_, node2->cid_, status, n_pts, weight, dist});
     }
@@ -786,7 +791,12 @@ class Oracle {
           continue;
         }
         ONode *new_node = g.nodes.at(g.node_id - 1);
-        wireEdge(node, new_node, type);
+        {
+          const uint64_t before = cnt_.collision_hits + cnt_.ellipse_hits, other = cnt_.wire_hits_other;
+          wireEdge(node, new_node, type);
+          cnt_.wire_hits_new += cnt_.collision_hits + cnt_.ellipse_hits - before;
+          cnt_.wire_hits_other = other;  // (wireEdge books every call as "other"; this one is not)
+        }
 
         if (param_.expand_dist - param_.robot_size < 0.25 * param_.expand_dist) {
           void *res2 = kd_.nearest_range2(g.node_tree, new_node->pos_[0], new_node->pos_[1],
@@ -1399,7 +1409,8 @@ void trg_oracle_counters(void *h, uint64_t *out) {
                   c.ellipse_hits,      c.wire_calls,     c.wire_evals,     c.wire_ok,
                   c.wire_gate,         c.wire_seg,       c.wire_empty,     c.wire_few,
                   c.wire_clamped,      c.expanded,       c.trials,         c.samples,
-                  c.created,           c.invalid_created, c.nn_node_queries, c.sample_hits};
+                  c.created,           c.invalid_created, c.nn_node_queries, c.sample_hits,
+                  c.wire_hits_new,     c.wire_hits_other};
   memcpy(out, v, sizeof(v));
 }
 void trg_oracle_reset_counters(void *h) { ((Oracle *)h)->cnt_ = OCounters(); }

@@ -191,6 +191,14 @@ def test_init_graph_parity(oa, request, case, replay):
     # algorithmic bytes of the sampling kernel == 12 B x the map points inside the discs of the
     # reference's own sampling loop (B_alg counted by the oracle's instrumentation)
     assert st["bytes_sample_kernel"] == 12 * c["sample_hits"], (st["bytes_sample_kernel"], c["sample_hits"])
+    if used_device:
+        # parent edges of the created nodes: the very wireEdge(node, new_node) calls of trg.cpp:425
+        assert st["bytes_spec_created"] == 12 * c["wire_hits_new"], (st["bytes_spec_created"], c["wire_hits_new"])
+        assert st["bytes_spec_kernel"] >= st["bytes_spec_created"]      # + speculation on merged candidates
+        # deferred edges: never fewer queries than the reference's other wireEdge calls; the excess is
+        # the second selection round (all remaining calls of a pair whose first call failed)
+        assert st["bytes_edge_kernel"] >= 12 * c["wire_hits_other"]
+        assert st["bytes_edge_kernel"] <= 12 * c["wire_hits_other"] * 1.02 + 12 * 2000
     assert st["nn_ties"] == 0 and st["map_nn_ties"] == 0
     # invariants of the reference
     assert (ge.state != -1).all() and (np.diff(ge.rowptr) >= 1).all()

@@ -262,6 +262,10 @@ struct StitchBufs;  // scratch of the tile-boundary stitch (trg_engine_stitch.in
 
 }  // namespace
 
+struct TrgEngine;
+namespace {
+TrgStatus stitch_fetch(TrgEngine *e);  // trg_engine_stitch.inc
+}
 struct TrgEngine {
   TrgParams prm{};
   int device = 0;
@@ -329,6 +333,8 @@ struct TrgEngine {
 
   Csr csr_global, csr_pre, csr_local;
   Csr csr_stitched;              // tiled builds: this tile's rows of the stitched global graph
+  bool stitched_on_device = false;  // ... their edge arrays are still in HBM only (fetched on export)
+  int stitched_edges = 0;
   bool dev_csr_valid = false;    // the cleaned global CSR of the last device build is still in HBM
   StitchBufs *stitch = nullptr;
   bool keep_preclean = false;    // instrumentation: snapshot the graph before cleanGraph
@@ -1921,6 +1927,8 @@ TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out) {
     c = &e->csr_pre;
   } else if (kind == TRG_KIND_STITCHED) {
     c = &e->csr_stitched;
+    const TrgStatus fs = stitch_fetch(e);
+    if (fs != TRG_OK) return fs;
   } else {
     // local graph: the global rows of the local member nodes
     c = &e->csr_local;

@@ -136,6 +136,7 @@ enum : int {
                       // still looks at this one)
   // statistics of the level just committed (k_level_commit)
   BFS_CTR_LDRAWS = 9, BFS_CTR_LSAMPLES = 10, BFS_CTR_LHITS_S = 11, BFS_CTR_LHITS_E = 12,
+  BFS_CTR_LHITS_NEW = 13,  // of LHITS_E: the parent edges of the nodes the level created
   BFS_CTR_COUNT = 16
 };
 enum : int {
@@ -162,7 +163,7 @@ struct alignas(16) SlotRec {
   float dist;      //   its length
   float cov[6];    //   covariance of its gather (xx xy xz yy yz zz), or cov[0] = weight when w_given
   int w_given;     //   1: the weight itself is stored (host re-evaluation after a map tie)
-  int pad;
+  int hits;        //   map points inside the edge's query radii (instrumentation)
 };
 struct alignas(16) NodeRec {  // per queued node of a level, 32 bytes
   int n_acc, n_draws;         // accepted samples, draws made

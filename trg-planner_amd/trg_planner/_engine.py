@@ -69,7 +69,8 @@ class TrgStats(C.Structure):
         ("bfs_max_spin", C.c_uint64), ("bfs_host_levels", C.c_uint64),
         ("map_nn_ties", C.c_uint64),
         ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double),
-        ("map_nn_resolved", C.c_uint64), ("map_nn_unresolved", C.c_uint64)]
+        ("map_nn_resolved", C.c_uint64), ("map_nn_unresolved", C.c_uint64),
+        ("bytes_spec_created", C.c_uint64)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
@@ -85,6 +86,7 @@ EXPORTS = [
     "trg_engine_check_reached", "trg_engine_check_replan", "trg_engine_set_tile",
     "trg_engine_voxel_filter", "trg_engine_plan_batch",
     "trg_engine_stitch_boundary", "trg_engine_stitch_cross", "trg_engine_stitch_assemble",
+    "trg_engine_graph_sizes",
 ]
 
 
@@ -158,6 +160,7 @@ def load_library():
     L.trg_engine_stitch_boundary.argtypes = [vp, fp, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int32, ip]
     L.trg_engine_stitch_cross.argtypes = [vp, C.c_int32, C.c_int32, vp, ip, vp, C.c_int32, ip]
     L.trg_engine_stitch_assemble.argtypes = [vp, C.c_int32, C.c_int32, ip, vp, C.c_int32]
+    L.trg_engine_graph_sizes.argtypes = [vp, C.c_int, ip, ip]
     L.trg_engine_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.trg_engine_fallback_reason.argtypes = [vp]
     L.trg_engine_fallback_reason.restype = C.c_char_p
@@ -310,9 +313,9 @@ class Engine:
 
     def graph_sizes(self, kind="global"):
         """(num_nodes, num_edges) without copying the arrays."""
-        v = TrgCsrView()
-        self._chk(self.L.trg_engine_export_csr(self.h, _KINDS[kind], C.byref(v)))
-        return int(v.num_nodes), int(v.num_edges)
+        V, E = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.trg_engine_graph_sizes(self.h, _KINDS[kind], C.byref(V), C.byref(E)))
+        return int(V.value), int(E.value)
 
     def node_xyz(self, kind="global"):
         """(V, 3) float32 node positions only (no edge arrays copied)."""

@@ -98,25 +98,45 @@ def stitch_device(eng, my_tile, core, cols, rows, dist=None, gather_dev=None):
     ntiles = cols * rows
     dev = torch.device("cuda", torch.cuda.current_device())
     gdev = dev if gather_dev is None else gather_dev
-    nb = eng.stitch_boundary(core, cols, rows, my_tile)
-    rec = torch.empty((max(nb, 1), 4), dtype=torch.int32, device=dev)
-    if nb:
-        eng.stitch_boundary(core, cols, rows, my_tile, rec.data_ptr(), nb)
-    all_rec, counts = allgatherv_t(rec[:nb].to(gdev), dist)
-    all_rec = all_rec.to(dev).contiguous()
-    rec_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-    # exchange of the tiles' node counts rides on the same collective shape (one int per rank)
+    bufs = getattr(eng, "_stitch_bufs", None)  # device scratch kept with the engine, grown on demand
+    if bufs is None:
+        bufs = eng._stitch_bufs = {"rec": torch.empty((1 << 14, 4), dtype=torch.int32, device=dev),
+                                   "edges": torch.empty((1 << 15, 6), dtype=torch.int32, device=dev)}
+    from ._engine import TrgError
+    while True:
+        rec = bufs["rec"]
+        try:
+            nb = eng.stitch_boundary(core, cols, rows, my_tile, rec.data_ptr(), rec.shape[0])
+            break
+        except TrgError as ex:
+            if ex.status != 8:  # TRG_ERR_CAPACITY
+                raise
+            need = eng.stitch_boundary(core, cols, rows, my_tile)
+            bufs["rec"] = torch.empty((2 * need, 4), dtype=torch.int32, device=dev)
+    # exchange 1: the boundary records, and riding behind them one row with this tile's node count
     V = eng.graph_sizes("global")[0]
-    vt, _ = allgatherv_t(torch.tensor([[V]], dtype=torch.int32, device=gdev), dist)
-    node_off = np.concatenate([[0], np.cumsum(vt.cpu().numpy().reshape(-1))]).astype(np.int32)
+    send = torch.cat([rec[:nb], torch.tensor([[V, 0, 0, 0]], dtype=torch.int32, device=dev)], 0)
+    got, counts = allgatherv_t(send.to(gdev), dist)
     if len(counts) != ntiles:  # single process: nothing to stitch against
-        eng.stitch_assemble(0, 1, node_off[:2], None, 0)
+        node_off = np.array([0, V], np.int32)
+        eng.stitch_assemble(0, 1, node_off, None, 0)
         return dict(n_boundary=0, n_cross=0, node_offsets=node_off, backend="none")
+    ends = np.cumsum(counts)
+    got = got.to(dev)
+    node_off = np.concatenate([[0], np.cumsum(got[torch.as_tensor(ends - 1, device=dev), 0].cpu().numpy())]
+                              ).astype(np.int32)
+    all_rec = torch.cat([got[e - c:e - 1] for e, c in zip(ends, counts)], 0).contiguous()
+    rec_off = np.concatenate([[0], np.cumsum([c - 1 for c in counts])]).astype(np.int32)
     torch.cuda.synchronize()
-    nc = eng.stitch_cross(my_tile, ntiles, all_rec.data_ptr(), rec_off)
-    edges = torch.empty((max(nc, 1), 6), dtype=torch.int32, device=dev)
-    if nc:
-        nc = eng.stitch_cross(my_tile, ntiles, all_rec.data_ptr(), rec_off, edges.data_ptr(), nc)
+    while True:
+        edges = bufs["edges"]
+        try:
+            nc = eng.stitch_cross(my_tile, ntiles, all_rec.data_ptr(), rec_off, edges.data_ptr(), edges.shape[0])
+            break
+        except TrgError as ex:
+            if ex.status != 8:
+                raise
+            bufs["edges"] = torch.empty((2 * edges.shape[0], 6), dtype=torch.int32, device=dev)
     all_edges, ecounts = allgatherv_t(edges[:nc].to(gdev), dist)
     all_edges = all_edges.to(dev).contiguous()
     torch.cuda.synchronize()
