@@ -673,9 +673,9 @@ struct TiePoint {
 TrgStatus ensure_tie_scratch(TrgEngine *e) {
   if (e->mt_set_d) return TRG_OK;
   HIPCHK(e, hipMalloc((void **)&e->mt_set_d, sizeof(MapTieSet)));
-  HIPCHK(e, hipMalloc((void **)&e->mt_key_d, sizeof(unsigned long long)));
+  HIPCHK(e, hipMalloc((void **)&e->mt_key_d, 4 * sizeof(unsigned long long)));
   HIPCHK(e, hipHostMalloc((void **)&e->mt_set_h, sizeof(MapTieSet), hipHostMallocDefault));
-  HIPCHK(e, hipHostMalloc((void **)&e->mt_key_h, sizeof(unsigned long long), hipHostMallocDefault));
+  HIPCHK(e, hipHostMalloc((void **)&e->mt_key_h, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   return TRG_OK;
 }
 
@@ -685,16 +685,17 @@ TrgStatus region_root(TrgEngine *e, const DevMap &m, const float lo[2], const fl
   hipStream_t s = e->s_main;
   HIPCHK(e, hipMemsetAsync(e->mt_key_d, 0xFF, sizeof(unsigned long long), s));
   launch_region_min_perm(m.view, lo[0], hi[0], lo[1], hi[1], perm_gt, e->mt_key_d, s);
-  HIPCHK(e, hipMemcpyAsync(e->mt_key_h, e->mt_key_d, sizeof(unsigned long long),
+  // one copy, one synchronisation per descent step: the key and the winner's (x, y) together
+  HIPCHK(e, hipMemcpyAsync(e->mt_key_h, e->mt_key_d + 2, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
-  const unsigned long long key = *e->mt_key_h;
+  const unsigned long long key = e->mt_key_h[0], xy = e->mt_key_h[1];
   *none = key == ~0ull;
   if (*none) return TRG_OK;
-  const size_t sidx = (size_t)(key & 0xFFFFFFFFull);
   out->perm = (int)(key >> 32);
-  HIPCHK(e, hipMemcpy(&out->x, m.x + sidx, sizeof(float), hipMemcpyDeviceToHost));
-  HIPCHK(e, hipMemcpy(&out->y, m.y + sidx, sizeof(float), hipMemcpyDeviceToHost));
+  const uint32_t xb = (uint32_t)(xy & 0xFFFFFFFFull), yb = (uint32_t)(xy >> 32);
+  memcpy(&out->x, &xb, sizeof(float));
+  memcpy(&out->y, &yb, sizeof(float));
   return TRG_OK;
 }
 

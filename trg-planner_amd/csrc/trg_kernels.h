@@ -116,6 +116,8 @@ void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, co
 // exact nearest-point tie-break helpers (rare path, see map_nn_exact in trg_engine.cpp)
 void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieSet *d_out,
                          hipStream_t s);
+// d_key: 4 words; [0] = smallest (original index << 32 | sorted index) (preset to ~0), result copy in
+// [2] with the winner's (x, y) bit patterns in [3]
 void launch_region_min_perm(const MapView &m, float lox, float hix, float loy, float hiy,
                             int perm_gt, unsigned long long *d_key, hipStream_t s);
 // Speculative parent edges node -> sample for every accepted sample of a chunk:
@@ -158,13 +160,15 @@ struct alignas(16) SlotRec {
   float x, y, z;   // accepted sample: position and elevation of the nearest map point
   float d0sq;      // squared distance to the nearest node that existed before the level
   int nn0;         // that node (-1: none in reach)
-  int cls;         // 0 unused slot, 1 a pre-level node within robot_size, 2 candidate for a new node
+  int cls;         // low byte: 0 unused slot, 1 a pre-level node within robot_size, 2 candidate for a
+                   // new node; SLOT_TIE: the nearest pre-level node was not unique
   int status;      // speculative parent edge (candidates): EDGE_* code and flags
   float dist;      //   its length
   float cov[6];    //   covariance of its gather (xx xy xz yy yz zz), or cov[0] = weight when w_given
   int w_given;     //   1: the weight itself is stored (host re-evaluation after a map tie)
   int hits;        //   map points inside the edge's query radii (instrumentation)
 };
+enum : int { SLOT_CLS_MASK = 0xFF, SLOT_TIE = 0x100 };
 struct alignas(16) NodeRec {  // per queued node of a level, 32 bytes
   int n_acc, n_draws;         // accepted samples, draws made
   int hits_sample, hits_spec; // map points inside its sampling discs / speculative-edge queries

@@ -1553,6 +1553,20 @@ __global__ __launch_bounds__(256) void k_region_min_perm(MapView m, float lox, f
   }
 }
 
+// key -> (key, x, y) of the winning point, so that the host needs ONE copy per descent step
+__global__ void k_region_fetch(MapView m, const unsigned long long *key, unsigned long long *out) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long k = *key;
+  out[0] = k;
+  float x = 0.0f, y = 0.0f;
+  if (k != ~0ull) {
+    const size_t sidx = (size_t)(k & 0xFFFFFFFFull);
+    x = m.x[sidx];
+    y = m.y[sidx];
+  }
+  out[1] = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
+}
+
 // LDS per wave of the edge kernels: x, y, z tile + hit buffer (4 * TCAP floats = 8 KB); the hit
 // buffer doubles as the scratch of the global-memory fallback, whose capacity is therefore TCAP.
 static_assert(TCAP % WAVE == 0, "tile capacity is a whole number of wave sweeps");
@@ -2050,6 +2064,7 @@ void launch_region_min_perm(const MapView &m, float lox, float hix, float loy, f
   int rows = m.H < 2048 ? m.H : 2048;
   hipLaunchKernelGGL(k_region_min_perm, dim3(rows), dim3(256), 0, s, m, lox, hix, loy, hiy, perm_gt,
                      d_key);
+  hipLaunchKernelGGL(k_region_fetch, dim3(1), dim3(64), 0, s, m, (const unsigned long long *)d_key, d_key + 2);
 }
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
                        const int *n_acc, const float *sx, const float *sy, const float *sz,
