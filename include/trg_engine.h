@@ -245,7 +245,8 @@ TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size
 /* ---- options ----------------------------------------------------------------------------------- */
 /* "replay" = "device" (default: BFS, dedupe and CSR on the GPU when expandGraph's step 3 is off,
  * trg.cpp:429) | "host" (sequential replay on the host, the only mode for step-3 configs);
- * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot).  Both modes give identical
+ * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot); "defer_overlap" = "0" | "1"
+ * (device BFS: deferred wireEdge evaluations pipelined behind the level loop on a second stream).  Both modes give identical
  * graphs; the env var TRG_REPLAY=host sets the default.  Test hooks (never change results):
  * "debug_tie_every" = n (treat every n-th BFS level as tie-affected -> host level replay),
  * "debug_gate_margin" = x (widen the band of slope gates left to the host's libm),

@@ -177,10 +177,12 @@ inline int kd_first_of_two(const float *px, const float *py, int K, float qx, fl
   if (A == B) return A;
   const float q[2] = {qx, qy};
   auto coord = [&](int n, int ax) { return ax == 0 ? px[n] : py[n]; };
-  std::vector<int> cur_list, next_list;
-  bool implicit = true;  // first pass: the candidate list is [1, K)
+  // The common path is walked with ONE forward scan over the insertion order: the subtree below
+  // `cur` on the side of A and B is the half-open box [lo, hi); its root is the first later node
+  // inside the box (children are inserted after their parents).  O(K), no allocation.
+  float lo[2] = {-INFINITY, -INFINITY}, hi[2] = {INFINITY, INFINITY};
   int cur = 0, axis = 0;
-  for (int depth = 0; depth < K + 2; ++depth) {
+  for (;;) {
     const float split = coord(cur, axis);
     const bool near_is_left = (q[axis] - split) <= 0;
     if (cur == A || cur == B) {
@@ -191,28 +193,18 @@ inline int kd_first_of_two(const float *px, const float *py, int K, float qx, fl
     }
     const bool a_left = coord(A, axis) < split, b_left = coord(B, axis) < split;
     if (a_left != b_left) return (a_left == near_is_left) ? A : B;
-    // same side: keep the candidates on that side, the subtree root is the smallest index
-    next_list.clear();
-    int best = -1;
-    auto consider = [&](int n) {
-      if (n == cur) return;
-      if ((coord(n, axis) < split) == a_left) {
-        next_list.push_back(n);
-        if (best < 0 || n < best) best = n;
-      }
-    };
-    if (implicit) {
-      for (int n = 1; n < K; ++n) consider(n);
-      implicit = false;
-    } else {
-      for (int n : cur_list) consider(n);
-    }
-    if (best < 0) return A < B ? A : B;  // cannot happen: A and B are on this side
-    cur_list.swap(next_list);
-    cur = best;
+    // same side: descend into it (kd_insert sends `<` to the left, kdtree.c:190)
+    if (a_left)
+      hi[axis] = split;
+    else
+      lo[axis] = split;
     axis ^= 1;
+    int n = cur + 1;
+    for (; n < K; ++n)
+      if (px[n] >= lo[0] && px[n] < hi[0] && py[n] >= lo[1] && py[n] < hi[1]) break;
+    if (n >= K) return A < B ? A : B;  // cannot happen: A and B are inside the box
+    cur = n;
   }
-  return A < B ? A : B;
 }
 
 // winner among a set of nodes that all have the minimal squared distance to (qx, qy)

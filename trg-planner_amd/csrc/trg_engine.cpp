@@ -339,6 +339,8 @@ struct TrgEngine {
   StitchBufs *stitch = nullptr;
   bool keep_preclean = false;    // instrumentation: snapshot the graph before cleanGraph
   bool use_device_bfs = true;    // device-resident BFS when expandGraph's step 3 is disabled
+  bool defer_overlap = false;    // deferred edge evaluations pipelined behind the level loop on a 2nd stream
+                                 // (measured: the loop loses more than the pipeline gains; kept as an option)
   bool pool_valid = true;        // e->edges mirrors csr_global
   bool host_grid_valid = true;   // e->grid holds the current node set
   bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
@@ -1550,8 +1552,22 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
   if (e->arch.rfind("gfx950", 0) != 0) {
     return e->fail(TRG_ERR_DEVICE, "kernels are built for gfx950 only, device is " + e->arch);
   }
-  HIPCHK(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
-  HIPCHK(e, hipStreamCreateWithFlags(&e->s_edge, hipStreamNonBlocking));
+  {
+    int pr_least = 0, pr_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+    HIPCHK(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+    // TRG_EDGE_CU_MASK=n: the second stream is confined to n compute units (experiment)
+    const char *cm = getenv("TRG_EDGE_CU_MASK");
+    int ncu_edge = cm ? atoi(cm) : 0;
+    if (ncu_edge > 0) {
+      uint32_t mask[8] = {0};
+      const int stride = 256 / std::max(1, std::min(ncu_edge, 256));
+      for (int k = 0; k < ncu_edge && k * stride < 256; ++k) mask[(k * stride) / 32] |= 1u << ((k * stride) % 32);
+      HIPCHK(e, hipExtStreamCreateWithCUMask(&e->s_edge, 8, mask));
+    } else {
+      HIPCHK(e, hipStreamCreateWithPriority(&e->s_edge, hipStreamNonBlocking, pr_least));
+    }
+  }
   HIPCHK(e, hipMalloc((void **)&e->d_ctr, COUNTER_SHARDS * sizeof(DeviceCounters)));
   HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
   HIPCHK(e, hipMalloc((void **)&e->d_bounds, 4 * sizeof(unsigned)));
@@ -1808,6 +1824,10 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_spec_bound") {
     e->debug_spec_bound = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "defer_overlap") {
+    e->defer_overlap = v != "0";
     return TRG_OK;
   }
   if (k == "debug_stall_level") {

@@ -139,6 +139,7 @@ enum : int {
   // statistics of the level just committed (k_level_commit)
   BFS_CTR_LDRAWS = 9, BFS_CTR_LSAMPLES = 10, BFS_CTR_LHITS_S = 11, BFS_CTR_LHITS_E = 12,
   BFS_CTR_LHITS_NEW = 13,  // of LHITS_E: the parent edges of the nodes the level created
+  BFS_CTR_NUNC2 = 14,      // uncertain gates of the deferred evaluations (third list)
   BFS_CTR_COUNT = 16
 };
 enum : int {
@@ -252,11 +253,14 @@ void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int 
                                  bool stall_test = false);
 // weights of the edges to the nodes [1, V) the BFS created (covariance -> SVD -> weight)
 void launch_node_weights(const BfsDev &B, int V, hipStream_t s);
+// deferred wireEdge evaluations of the calls list[0..count) (count_dev != nullptr: count is an upper
+// bound, the kernels take min(count, *count_dev))
 void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, const int *list, int count,
-                       DeviceCounters *ctr, hipStream_t s);
-void launch_first_insert(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
-void launch_calls_select(const FinDev &F, const BfsDev &B, long long ncalls, int round, int *flag,
-                         int *off, int *scan_tmp, int *list, hipStream_t s);
+                       const int *count_dev, DeviceCounters *ctr, hipStream_t s);
+void launch_first_insert(const FinDev &F, const BfsDev &B, long long c0, long long c1, hipStream_t s);
+void launch_calls_select(const FinDev &F, const BfsDev &B, long long c0, long long c1, int round,
+                         int *flag, int *off, int *scan_tmp, int *list, unsigned long long *total,
+                         hipStream_t s);
 void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
 void launch_fin_scatter_sort(const FinDev &F, const BfsDev &B, long long ncalls, int V, hipStream_t s);
 void launch_fin_clean(const FinDev &F, const BfsDev &B, const int *new2old, const int *old2new, int Vn,
