@@ -13,7 +13,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC, "libtrg_engine.so")
+# TRG_ENGINE_LIB: another build of the same library (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("TRG_ENGINE_LIB") or os.path.join(CSRC, "libtrg_engine.so")
 
 KIND_GLOBAL, KIND_LOCAL, KIND_PRECLEAN, KIND_STITCHED = 0, 1, 2, 3
 _KINDS = {"global": KIND_GLOBAL, "local": KIND_LOCAL, "preclean": KIND_PRECLEAN,
