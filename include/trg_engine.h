@@ -149,6 +149,9 @@ typedef struct TrgStats {
                                   in the reference's map-tree visiting order (kdtree.c:303-362) */
   uint64_t map_nn_unresolved;  /* ties left at "lowest cloud index" (more than 16 points tied, or more
                                   than 256 tied samples in one launch) -- 0 in practice */
+  uint64_t bfs_tie_fixups;     /* BFS levels whose only trouble was a distance tie among nodes that existed
+                                  before the level: the reference's winner was handed to the device and
+                                  resolve + commit ran again (no host replay) */
   uint64_t bytes_spec_created; /* device path: the part of bytes_spec_kernel spent on the parent edges of
                                   the nodes that were created -- the wireEdge(node, new_node) calls the
                                   reference itself evaluates (trg.cpp:425); the rest of

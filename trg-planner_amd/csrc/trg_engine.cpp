@@ -329,7 +329,7 @@ struct TrgEngine {
   size_t sy_cap = 0;
   // exact nearest-map-point tie-break scratch (map_nn_exact)
   MapTieSet *mt_set_d = nullptr, *mt_set_h = nullptr;
-  unsigned long long *mt_key_d = nullptr, *mt_key_h = nullptr;
+  MapTieWalk *mt_walk_d = nullptr, *mt_walk_h = nullptr;
 
   Csr csr_global, csr_pre, csr_local;
   Csr csr_stitched;              // tiled builds: this tile's rows of the stitched global graph
@@ -675,66 +675,44 @@ struct TiePoint {
 TrgStatus ensure_tie_scratch(TrgEngine *e) {
   if (e->mt_set_d) return TRG_OK;
   HIPCHK(e, hipMalloc((void **)&e->mt_set_d, sizeof(MapTieSet)));
-  HIPCHK(e, hipMalloc((void **)&e->mt_key_d, 4 * sizeof(unsigned long long)));
+  HIPCHK(e, hipMalloc((void **)&e->mt_walk_d, sizeof(MapTieWalk)));
   HIPCHK(e, hipHostMalloc((void **)&e->mt_set_h, sizeof(MapTieSet), hipHostMallocDefault));
-  HIPCHK(e, hipHostMalloc((void **)&e->mt_key_h, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  HIPCHK(e, hipHostMalloc((void **)&e->mt_walk_h, sizeof(MapTieWalk), hipHostMallocDefault));
   return TRG_OK;
 }
 
-// root of the subtree covering [lo, hi) below the ancestor `perm_gt`; *none when the region is empty
-TrgStatus region_root(TrgEngine *e, const DevMap &m, const float lo[2], const float hi[2], int perm_gt,
-                      TiePoint *out, bool *none) {
-  hipStream_t s = e->s_main;
-  HIPCHK(e, hipMemsetAsync(e->mt_key_d, 0xFF, sizeof(unsigned long long), s));
-  launch_region_min_perm(m.view, lo[0], hi[0], lo[1], hi[1], perm_gt, e->mt_key_d, s);
-  // one copy, one synchronisation per descent step: the key and the winner's (x, y) together
-  HIPCHK(e, hipMemcpyAsync(e->mt_key_h, e->mt_key_d + 2, 2 * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipStreamSynchronize(s));
-  const unsigned long long key = e->mt_key_h[0], xy = e->mt_key_h[1];
-  *none = key == ~0ull;
-  if (*none) return TRG_OK;
-  out->perm = (int)(key >> 32);
-  const uint32_t xb = (uint32_t)(xy & 0xFFFFFFFFull), yb = (uint32_t)(xy >> 32);
-  memcpy(&out->x, &xb, sizeof(float));
-  memcpy(&out->y, &yb, sizeof(float));
-  return TRG_OK;
-}
-
-// which of the tied points A, B the nearest-neighbour search for q visits first: 0 = A, 1 = B
+// which of the tied points A, B the nearest-neighbour search for q visits first: 0 = A, 1 = B.  The
+// walk (region scan + decision per tree level, ~30-50 levels on a 10 M-point map) runs on the device
+// without the host in between: a batch of steps is enqueued blindly, steps after the decision return
+// at once.
 TrgStatus map_first_of_two(TrgEngine *e, const DevMap &m, float qx, float qy, const TiePoint &A,
                            const TiePoint &B, int *first) {
-  const float q[2] = {qx, qy};
-  float lo[2] = {-INFINITY, -INFINITY}, hi[2] = {INFINITY, INFINITY};
-  TiePoint cur{};
-  bool none = false;
-  TrgStatus st = region_root(e, m, lo, hi, -1, &cur, &none);
-  if (st != TRG_OK) return st;
-  int axis = 0;
-  for (int depth = 0; depth < 100000 && !none; ++depth) {
-    const float split = axis ? cur.y : cur.x;
-    const bool near_is_left = (q[axis] - split) <= 0;
-    const float ca = axis ? A.y : A.x, cb = axis ? B.y : B.x;
-    if (cur.perm == A.perm || cur.perm == B.perm) {
-      // the other point lies in cur's subtree: it is visited before cur iff it is on the nearer side
-      const bool cur_is_a = cur.perm == A.perm;
-      const bool other_left = (cur_is_a ? cb : ca) < split;
-      const bool other_first = other_left == near_is_left;
-      *first = cur_is_a ? (other_first ? 1 : 0) : (other_first ? 0 : 1);
+  hipStream_t s = e->s_main;
+  MapTieWalk w{};
+  w.key = ~0ull;
+  w.lo[0] = w.lo[1] = -INFINITY;
+  w.hi[0] = w.hi[1] = INFINITY;
+  w.cur_perm = -1;
+  w.axis = 0;
+  w.qx = qx;
+  w.qy = qy;
+  w.aperm = A.perm;
+  w.bperm = B.perm;
+  w.ax = A.x;
+  w.ay = A.y;
+  w.bx = B.x;
+  w.by = B.y;
+  *e->mt_walk_h = w;
+  HIPCHK(e, hipMemcpyAsync(e->mt_walk_d, e->mt_walk_h, sizeof(MapTieWalk), hipMemcpyHostToDevice, s));
+  for (int batch = 0; batch < 64; ++batch) {
+    launch_map_tie_walk(m.view, e->mt_walk_d, batch == 0 ? 48 : 32, s);
+    HIPCHK(e, hipMemcpyAsync(e->mt_walk_h, e->mt_walk_d, sizeof(MapTieWalk), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    if (e->mt_walk_h->done == 1) {
+      *first = e->mt_walk_h->first;
       return TRG_OK;
     }
-    const bool a_left = ca < split, b_left = cb < split;
-    if (a_left != b_left) {
-      *first = (a_left == near_is_left) ? 0 : 1;
-      return TRG_OK;
-    }
-    if (a_left)
-      hi[axis] = split;
-    else
-      lo[axis] = split;
-    st = region_root(e, m, lo, hi, cur.perm, &cur, &none);
-    if (st != TRG_OK) return st;
-    axis ^= 1;
+    if (e->mt_walk_h->done) break;
   }
   return e->fail(TRG_ERR_DEVICE, "nearest-point tie-break lost its candidates (internal error)");
 }
@@ -1615,9 +1593,9 @@ void trg_engine_destroy(TrgEngine *e) {
     }
     if (e->sy_mid) (void)hipFree(e->sy_mid);
     if (e->mt_set_d) (void)hipFree(e->mt_set_d);
-    if (e->mt_key_d) (void)hipFree(e->mt_key_d);
+    if (e->mt_walk_d) (void)hipFree(e->mt_walk_d);
     if (e->mt_set_h) (void)hipHostFree(e->mt_set_h);
-    if (e->mt_key_h) (void)hipHostFree(e->mt_key_h);
+    if (e->mt_walk_h) (void)hipHostFree(e->mt_walk_h);
     if (e->bfs) {
       e->bfs->release();
       delete e->bfs;

@@ -116,10 +116,21 @@ void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, co
 // exact nearest-point tie-break helpers (rare path, see map_nn_exact in trg_engine.cpp)
 void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieSet *d_out,
                          hipStream_t s);
-// d_key: 4 words; [0] = smallest (original index << 32 | sorted index) (preset to ~0), result copy in
-// [2] with the winner's (x, y) bit patterns in [3]
-void launch_region_min_perm(const MapView &m, float lox, float hix, float loy, float hiy,
-                            int perm_gt, unsigned long long *d_key, hipStream_t s);
+// State of one walk down the map's insertion tree (which of two tied points kd_nearest visits first):
+// the steps run on the device back to back, the host only looks at the final state.
+struct MapTieWalk {
+  unsigned long long key;  // smallest (original index << 32 | sorted index) of the current scan; ~0 = none
+  float lo[2], hi[2];      // half-open region of the current subtree
+  int cur_perm;            // its ancestor (points inserted later than this one are in the subtree)
+  int axis;
+  float qx, qy;
+  int aperm, bperm;
+  float ax, ay, bx, by;
+  int done;                // 0 walking, 1 decided (first = 0: A, 1: B), 2 lost its candidates
+  int first;
+  int steps;
+};
+void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int steps, hipStream_t s);
 // Speculative parent edges node -> sample for every accepted sample of a chunk:
 //   node_xyz[count*3]; slot = node*S + j evaluated iff j < n_acc[node]
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
@@ -145,7 +156,9 @@ enum : int {
 enum : int {
   BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
   BFS_ERR_HASH = 16, BFS_ERR_LEVEL_TOO_BIG = 32, BFS_ERR_CLEAN = 64,
-  BFS_ERR_STALL = 128  // k_level_resolve's bounded wait ran out: the level is replayed on the host
+  BFS_ERR_STALL = 128,  // k_level_resolve's bounded wait ran out: the level is replayed on the host
+  BFS_ERR_TIE_CLS = 256 // a sample's nearest PRE-LEVEL node was not unique (k_level_sample; the slot
+                        // carries SLOT_TIE): the host picks the reference's winner, resolve + commit rerun
 };
 enum : int { CALL_NONE = -2, CALL_PENDING = -1 };
 

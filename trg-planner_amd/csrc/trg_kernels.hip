@@ -1521,9 +1521,12 @@ __global__ __launch_bounds__(WAVE) void k_map_tied_set(MapView m, float qx, floa
 // inserted as point number perm_gt: the region's point with the smallest original index above
 // perm_gt (kd_insert descends with `<` to the left, kdtree.c:179-198, so a subtree is exactly the
 // later points of its half-open region).  key = (original index << 32 | sorted index), atomicMin.
-__global__ __launch_bounds__(256) void k_region_min_perm(MapView m, float lox, float hix, float loy,
-                                                         float hiy, int perm_gt,
-                                                         unsigned long long *key) {
+// One step of the walk down the (never built) insertion tree of the map, region and ancestor taken
+// from the walk state in device memory (the host enqueues the steps without looking at them).
+__global__ __launch_bounds__(256) void k_region_min_perm(MapView m, MapTieWalk *st) {
+  if (st->done) return;
+  const float lox = st->lo[0], hix = st->hi[0], loy = st->lo[1], hiy = st->hi[1];
+  const int perm_gt = st->cur_perm;
   const int cy0 = cell_coord(loy, m.y0, m.inv_g, m.H), cy1 = cell_coord(hiy, m.y0, m.inv_g, m.H);
   const int cx0 = cell_coord(lox, m.x0, m.inv_g, m.W), cx1 = cell_coord(hix, m.x0, m.inv_g, m.W);
   __shared__ unsigned long long red[4];
@@ -1549,22 +1552,51 @@ __global__ __launch_bounds__(256) void k_region_min_perm(MapView m, float lox, f
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < 4; ++i) best = red[i] < best ? red[i] : best;
-    if (best != ~0ull) atomicMin(key, best);
+    if (best != ~0ull) atomicMin(&st->key, best);
   }
 }
 
-// key -> (key, x, y) of the winning point, so that the host needs ONE copy per descent step
-__global__ void k_region_fetch(MapView m, const unsigned long long *key, unsigned long long *out) {
-  if (threadIdx.x != 0) return;
-  const unsigned long long k = *key;
-  out[0] = k;
-  float x = 0.0f, y = 0.0f;
-  if (k != ~0ull) {
-    const size_t sidx = (size_t)(k & 0xFFFFFFFFull);
-    x = m.x[sidx];
-    y = m.y[sidx];
+// The decision at the subtree root the scan found (map_first_of_two's loop body): which of the tied
+// points A, B the nearest-neighbour search for q visits first is settled at their lowest common
+// ancestor; otherwise the region shrinks to the side both lie on.
+__global__ void k_region_step(MapView m, MapTieWalk *st) {
+  if (threadIdx.x != 0 || st->done) return;
+  const unsigned long long key = st->key;
+  st->key = ~0ull;
+  st->steps++;
+  if (key == ~0ull) {  // empty region: cannot happen (A and B are inside); reported as unresolved
+    st->done = 2;
+    return;
   }
-  out[1] = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
+  const size_t sidx = (size_t)(key & 0xFFFFFFFFull);
+  const int cperm = (int)(key >> 32);
+  const float cx = m.x[sidx], cy = m.y[sidx];
+  const int axis = st->axis;
+  const float split = axis ? cy : cx;
+  const float q = axis ? st->qy : st->qx;
+  const bool near_is_left = (q - split) <= 0;
+  const float ca = axis ? st->ay : st->ax, cb = axis ? st->by : st->bx;
+  if (cperm == st->aperm || cperm == st->bperm) {
+    // the other point lies in cur's subtree: it is visited before cur iff it is on the nearer side
+    const bool cur_is_a = cperm == st->aperm;
+    const bool other_left = (cur_is_a ? cb : ca) < split;
+    const bool other_first = other_left == near_is_left;
+    st->first = cur_is_a ? (other_first ? 1 : 0) : (other_first ? 0 : 1);
+    st->done = 1;
+    return;
+  }
+  const bool a_left = ca < split, b_left = cb < split;
+  if (a_left != b_left) {
+    st->first = (a_left == near_is_left) ? 0 : 1;
+    st->done = 1;
+    return;
+  }
+  if (a_left)
+    st->hi[axis] = split;
+  else
+    st->lo[axis] = split;
+  st->cur_perm = cperm;
+  st->axis = axis ^ 1;
 }
 
 // LDS per wave of the edge kernels: x, y, z tile + hit buffer (4 * TCAP floats = 8 KB); the hit
@@ -2058,13 +2090,13 @@ void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieS
                          hipStream_t s) {
   hipLaunchKernelGGL(k_map_tied_set, dim3(1), dim3(WAVE), 0, s, m, qx, qy, r0, d_out);
 }
-void launch_region_min_perm(const MapView &m, float lox, float hix, float loy, float hiy,
-                            int perm_gt, unsigned long long *d_key, hipStream_t s) {
+void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int steps, hipStream_t s) {
   // one block per cell row of the region, at most 2048 blocks (rows are strided beyond that)
-  int rows = m.H < 2048 ? m.H : 2048;
-  hipLaunchKernelGGL(k_region_min_perm, dim3(rows), dim3(256), 0, s, m, lox, hix, loy, hiy, perm_gt,
-                     d_key);
-  hipLaunchKernelGGL(k_region_fetch, dim3(1), dim3(64), 0, s, m, (const unsigned long long *)d_key, d_key + 2);
+  const int rows = m.H < 2048 ? m.H : 2048;
+  for (int k = 0; k < steps; ++k) {
+    hipLaunchKernelGGL(k_region_min_perm, dim3(rows), dim3(256), 0, s, m, d_state);
+    hipLaunchKernelGGL(k_region_step, dim3(1), dim3(64), 0, s, m, d_state);
+  }
 }
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
                        const int *n_acc, const float *sx, const float *sy, const float *sz,
