@@ -246,9 +246,9 @@ def main():
             tpath = os.path.join(ROOT, "profiles", f"{tag}_{args.workload}_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
-                key = dom if dom in tj else dom.split("+")[0]
-                if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_dispatch"]
+                parts = dom.split("+")  # kernels timed together: one launch of each per level
+                if all(k in tj for k in parts):
+                    traffic = sum(tj[k]["hbm_bytes_per_dispatch"] for k in parts)
                     traffic_src = os.path.relpath(tpath, ROOT)
                     break
         out = {
