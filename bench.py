@@ -289,7 +289,8 @@ def main():
                 "used_device_bfs": st["used_device_bfs"], "bfs_fallbacks": st["bfs_fallbacks"],
                 "bfs_host_levels": st["bfs_host_levels"],
                 "bfs_max_spin": st["bfs_max_spin"], "ms_bfs_loop": st["ms_bfs_loop"],
-                "ms_deferred": st["ms_deferred"], "ms_set_map_total": st["ms_set_map_total"],
+                "ms_deferred": st["ms_deferred"], "ms_rare_events": st["ms_rare_events"],
+                "ms_set_map_total": st["ms_set_map_total"],
                 "map_nn_resolved": st["map_nn_resolved"], "map_nn_unresolved": st["map_nn_unresolved"],
                 "ms_stitch_rank0": stitch_info.get("ms_stitch_last", 0.0),
                 "fallback_reason": eng.fallback_reason,

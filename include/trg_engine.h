@@ -71,7 +71,7 @@ typedef struct TrgParams {
  * reference's `distr_(gen_) * 2 * M_PI` -> cos/sin would give for that draw, trg.cpp:395-397). */
 typedef struct TrgSampler {
   uint32_t seed;
-  int32_t table_bits; /* 8..20, default 16 */
+  int32_t table_bits; /* 2..20 (out of range: 16); few bits = few directions: degenerate, tie-rich graphs for tests */
 } TrgSampler;
 
 /* Read-only view of a built graph in CSR form (host memory owned by the engine, valid until the
@@ -156,6 +156,8 @@ typedef struct TrgStats {
                                   the nodes that were created -- the wireEdge(node, new_node) calls the
                                   reference itself evaluates (trg.cpp:425); the rest of
                                   bytes_spec_kernel is speculation on candidates that merged */
+  double ms_rare_events;       /* device path: wall time inside the level loop spent repairing rare events
+                                  (map-point ties, uncertain slope gates, node ties, host level replays) */
 } TrgStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -249,7 +251,9 @@ TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size
 /* "replay" = "device" (default: BFS, dedupe and CSR on the GPU when expandGraph's step 3 is off,
  * trg.cpp:429) | "host" (sequential replay on the host, the only mode for step-3 configs);
  * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot); "defer_overlap" = "0" | "1"
- * (device BFS: deferred wireEdge evaluations pipelined behind the level loop on a second stream).  Both modes give identical
+ * (device BFS: deferred wireEdge evaluations pipelined behind the level loop on a second stream);
+ * "tie_inplace" = "1" | "0" (device BFS: a nearest-node distance tie is settled for the affected slot alone on
+ * the committed level -- off: the whole level is replayed on the host).  All modes give identical
  * graphs; the env var TRG_REPLAY=host sets the default.  Test hooks (never change results):
  * "debug_tie_every" = n (treat every n-th BFS level as tie-affected -> host level replay),
  * "debug_gate_margin" = x (widen the band of slope gates left to the host's libm),

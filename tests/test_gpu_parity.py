@@ -292,6 +292,42 @@ def test_tie_levels_replayed_on_host_give_the_same_graph(oa, mountain_small):
     assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
 
 
+@pytest.mark.parametrize("bits", [2, 4, 5])
+@pytest.mark.parametrize("inplace", [1, 0])
+def test_natural_node_ties_settled_like_the_reference(oa, synth, bits, inplace):
+    """Real nearest-node ties, hundreds of them: with only 4 / 16 / 32 sampling directions the nodes
+    fall on a few lattices and samples sit at exactly the same fp32 distance from two of them.  The
+    reference's answer is its kd-tree's visiting order.  Default: the committed level stands and
+    the host decides just the tied slots (tie_inplace) or hands k_level_resolve the winner among
+    pre-level nodes (both counted in bfs_tie_fixups); tie_inplace=0, levels with more than
+    BFS_TIE_CAP tied slots, and ties that put the level's node set in doubt replay the level on the
+    host.  Every mode must equal the oracle."""
+    cloud = synth.mountain_cloud(260, 260, seed=5, amplitude=0.3)
+    prm = dict(oa.MOUNTAIN, sample_num=8)
+    start = [13.0, 13.0, 0.0]
+    e = _engine(prm)
+    e.set_sampler(33, bits)
+    e.set_option("keep_preclean", 1)
+    e.set_option("tie_inplace", inplace)
+    e.set_global_map(cloud)
+    e.init_graph(start)
+    st = e.stats()
+    assert st["used_device_bfs"] == 1 and st["bfs_fallbacks"] == 0, (st, e.fallback_reason)
+    assert st["nn_ties"] > 0, st
+    assert st["bfs_tie_fixups"] > 0, st  # (ties among pre-level nodes are always fixed in place)
+    if not inplace and bits > 2:
+        assert st["bfs_host_levels"] > 0, st
+    o = oa.Oracle(**prm)
+    o.set_sampler(33, 0, bits)
+    o.set_global_map(cloud)
+    assert o.init_graph(start)
+    assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL)
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
+    c = o.counters()
+    assert st["trials"] == c["trials"] and st["samples"] == c["samples"]
+    assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
+
+
 def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
     """k_bfs_resolve's inter-workgroup wait is bounded; when it runs out (BFS_ERR_STALL) the level is
     left PARTIALLY decided -- outcomes 0 / 7 in c_outcome, commit and emit have run on them.  The

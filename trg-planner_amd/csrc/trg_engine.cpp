@@ -347,6 +347,7 @@ struct TrgEngine {
   int debug_tie_every = 0;       // test hook: treat every n-th BFS level as tie-affected
   int debug_spec_bound = 0;      // test hook: cap the speculative sampling launch at n nodes
   int debug_fallback_level = -1; // test hook: the device BFS declines at this level
+  bool tie_inplace = true;       // node-distance ties settled slot by slot on the committed level (off: host level replay)
   int debug_stall_level = -1;    // test hook: k_bfs_resolve leaves one candidate of this level undecided
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
@@ -557,7 +558,7 @@ TrgStatus upload_and_build(TrgEngine *e, DevMap &m, const float *xyz, size_t n, 
 // ---- sampler table -----------------------------------------------------------------------------
 TrgStatus ensure_sampler(TrgEngine *e, const TrgSampler *smp) {
   TrgSampler want = smp ? *smp : e->sampler;
-  if (want.table_bits < 8 || want.table_bits > 20) want.table_bits = 16;
+  if (want.table_bits < 2 || want.table_bits > 20) want.table_bits = 16;
   e->sampler = want;
   if (e->table_bits_dev == want.table_bits && e->d_cos) return TRG_OK;
   const size_t n = (size_t)1 << want.table_bits;
@@ -683,8 +684,8 @@ TrgStatus ensure_tie_scratch(TrgEngine *e) {
 
 // which of the tied points A, B the nearest-neighbour search for q visits first: 0 = A, 1 = B.  The
 // walk (region scan + decision per tree level, ~30-50 levels on a 10 M-point map) runs on the device
-// without the host in between: a batch of steps is enqueued blindly, steps after the decision return
-// at once.
+// without the host in between: the first steps (regions of millions of points) one grid-wide kernel
+// each, enqueued blindly, the rest inside a single workgroup; steps after the decision return at once.
 TrgStatus map_first_of_two(TrgEngine *e, const DevMap &m, float qx, float qy, const TiePoint &A,
                            const TiePoint &B, int *first) {
   hipStream_t s = e->s_main;
@@ -705,7 +706,8 @@ TrgStatus map_first_of_two(TrgEngine *e, const DevMap &m, float qx, float qy, co
   *e->mt_walk_h = w;
   HIPCHK(e, hipMemcpyAsync(e->mt_walk_d, e->mt_walk_h, sizeof(MapTieWalk), hipMemcpyHostToDevice, s));
   for (int batch = 0; batch < 64; ++batch) {
-    launch_map_tie_walk(m.view, e->mt_walk_d, batch == 0 ? 48 : 32, s);
+    // (12 halvings leave ~N / 4096 points; an unbalanced walk just spends longer in the one-workgroup kernel)
+    launch_map_tie_walk(m.view, e->mt_walk_d, batch == 0 ? 12 : 0, 64, s);
     HIPCHK(e, hipMemcpyAsync(e->mt_walk_h, e->mt_walk_d, sizeof(MapTieWalk), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipStreamSynchronize(s));
     if (e->mt_walk_h->done == 1) {
@@ -1810,6 +1812,10 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_stall_level") {
     e->debug_stall_level = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "tie_inplace") {
+    e->tie_inplace = v != "0";
     return TRG_OK;
   }
   if (k == "debug_fallback_level") {

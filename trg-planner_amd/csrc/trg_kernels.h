@@ -129,8 +129,9 @@ struct MapTieWalk {
   int done;                // 0 walking, 1 decided (first = 0: A, 1: B), 2 lost its candidates
   int first;
   int steps;
+  int ticket;              // workgroups of the current grid step that have finished
 };
-void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int steps, hipStream_t s);
+void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int grid_steps, int block_steps, hipStream_t s);
 // Speculative parent edges node -> sample for every accepted sample of a chunk:
 //   node_xyz[count*3]; slot = node*S + j evaluated iff j < n_acc[node]
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
@@ -140,10 +141,12 @@ void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, i
 
 // ---- device-resident BFS (trg_bfs.inc, trg_level.inc) -------------------------------------------------
 constexpr int GRID_SLOTS = 4;      // nodes per grid cell (cell = robot_size, nodes are >= robot_size apart)
+constexpr int BFS_TIE_CAP = 64;    // tied slots of one level handed to the host one by one (more: the level is replayed)
 constexpr int BFS_UNC_CAP = 4096;  // uncertain slope gates handed to the host per sync point
 enum : int {
   BFS_CTR_V = 0, BFS_CTR_MNEXT = 1, BFS_CTR_NCAND = 2, BFS_CTR_NUNC = 3, BFS_CTR_ERR = 4,
-  BFS_CTR_DONE = 5,   // spare on the device; in the host copy: the stamp of the level (as word 15)
+  BFS_CTR_DONE = 5,   // in the host copy: the stamp of the level (as word 15)
+  BFS_CTR_NTIE = 5,   // on the device: entries of tie_list (slots whose nearest node was not unique)
   BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */,
   BFS_CTR_NUNC1 = 8,  // uncertain gates of odd levels (the next level is expanded while the host
                       // still looks at this one)
@@ -226,6 +229,7 @@ struct BfsDev {
   // uncertain slope gates for the host (2 x BFS_UNC_CAP, by level parity)
   int *unc_list;
   float *unc_rec;
+  int *tie_list;      // BFS_TIE_CAP slots of the current level that met an exact distance tie in k_level_resolve
   MapTieRec *mt_rec;  // 2 x MAPTIE_CAP records (level parity), counts in ctrs[BFS_CTR_NMAPTIE + parity]
   // call log (one record per sample slot, in program order)
   int *call_n1, *call_n2, *call_status;
@@ -248,6 +252,7 @@ struct FinDev {
 };
 
 void launch_bfs_insert_nodes(const BfsDev &B, int first, int count, hipStream_t s);
+void launch_bfs_clear_tie(const BfsDev &B, hipStream_t s);
 void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
 // ---- one BFS level in three kernels (trg_level.inc) ---------------------------------------------
 constexpr int LEVEL_MAX_SAMPLES = 64;  // sample_num the level kernels support
@@ -258,7 +263,7 @@ constexpr int LEVEL_MAX_SAMPLES = 64;  // sample_num the level kernels support
 void launch_level_expand(const MapView &m, QueryParams p, const float *cos_t, const float *sin_t,
                          int table_bits, uint32_t seed, uint32_t epoch, const BfsDev &B, int count,
                          const int *count_dev, int node_base, int parity, int tag, int pub_stamp,
-                         DeviceCounters *ctr, hipStream_t s);
+                         DeviceCounters *ctr, hipStream_t s, int which = 3);
 // whether the level kernels can serve these parameters (window of the node grid, sample count)
 bool level_kernels_support(const QueryParams &p, float grid_cell);
 void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int new_state,

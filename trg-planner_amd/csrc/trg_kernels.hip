@@ -1252,11 +1252,21 @@ __global__ __launch_bounds__(256) void k_bounds(const float *xyz, size_t n, size
     mxx = max(mxx, (unsigned)__shfl_xor((int)mxx, m));
     mxy = max(mxy, (unsigned)__shfl_xor((int)mxy, m));
   }
+  // one set of atomics per workgroup: same-address atomics serialise (~13 ns each)
+  __shared__ unsigned red[4][4];
+  const int w = threadIdx.x >> 6;
   if (lane_id() == 0) {
-    atomicMin(&b[0], mnx);
-    atomicMin(&b[1], mny);
-    atomicMax(&b[2], mxx);
-    atomicMax(&b[3], mxy);
+    red[w][0] = mnx;
+    red[w][1] = mny;
+    red[w][2] = mxx;
+    red[w][3] = mxy;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&b[0], min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0])));
+    atomicMin(&b[1], min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1])));
+    atomicMax(&b[2], max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2])));
+    atomicMax(&b[3], max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3])));
   }
 }
 
@@ -1520,24 +1530,25 @@ __global__ __launch_bounds__(WAVE) void k_map_tied_set(MapView m, float qx, floa
 // The kd-tree node that roots the subtree of the region [lox, hix) x [loy, hiy), below an ancestor
 // inserted as point number perm_gt: the region's point with the smallest original index above
 // perm_gt (kd_insert descends with `<` to the left, kdtree.c:179-198, so a subtree is exactly the
-// later points of its half-open region).  key = (original index << 32 | sorted index), atomicMin.
-// One step of the walk down the (never built) insertion tree of the map, region and ancestor taken
-// from the walk state in device memory (the host enqueues the steps without looking at them).
-__global__ __launch_bounds__(256) void k_region_min_perm(MapView m, MapTieWalk *st) {
-  if (st->done) return;
-  const float lox = st->lo[0], hix = st->hi[0], loy = st->lo[1], hiy = st->hi[1];
-  const int perm_gt = st->cur_perm;
-  const int cy0 = cell_coord(loy, m.y0, m.inv_g, m.H), cy1 = cell_coord(hiy, m.y0, m.inv_g, m.H);
-  const int cx0 = cell_coord(lox, m.x0, m.inv_g, m.W), cx1 = cell_coord(hix, m.x0, m.inv_g, m.W);
-  __shared__ unsigned long long red[4];
+// later points of its half-open region).  key = (original index << 32 | sorted index).
+// This is one step of the walk down the (never built) insertion tree of the map; region and ancestor
+// are taken from the walk state in device memory, the host enqueues the steps without looking.
+struct WalkRegion {
+  float lox, hix, loy, hiy;
+  int perm_gt;
+};
+__device__ __forceinline__ unsigned long long region_scan_rows(const MapView &m, const WalkRegion &g, int row0,
+                                                               int row_stride, int tid, int nthreads) {
+  const int cy0 = cell_coord(g.loy, m.y0, m.inv_g, m.H), cy1 = cell_coord(g.hiy, m.y0, m.inv_g, m.H);
+  const int cx0 = cell_coord(g.lox, m.x0, m.inv_g, m.W), cx1 = cell_coord(g.hix, m.x0, m.inv_g, m.W);
   unsigned long long best = ~0ull;
-  for (int cy = cy0 + (int)blockIdx.x; cy <= cy1; cy += (int)gridDim.x) {
+  for (int cy = cy0 + row0; cy <= cy1; cy += row_stride) {
     const int s = m.cell_start[cy * m.W + cx0];
     const int e = m.cell_start[cy * m.W + cx1 + 1];
-    for (int i = s + (int)threadIdx.x; i < e; i += 256) {
+    for (int i = s + tid; i < e; i += nthreads) {
       const float x = m.x[i], y = m.y[i];
       const int pm = m.perm[i];
-      if (x >= lox && x < hix && y >= loy && y < hiy && pm > perm_gt) {
+      if (x >= g.lox && x < g.hix && y >= g.loy && y < g.hiy && pm > g.perm_gt) {
         const unsigned long long k = ((unsigned long long)(unsigned)pm << 32) | (unsigned)i;
         best = k < best ? k : best;
       }
@@ -1548,21 +1559,13 @@ __global__ __launch_bounds__(256) void k_region_min_perm(MapView m, MapTieWalk *
     const unsigned long long o = __shfl_xor(best, msk);
     best = o < best ? o : best;
   }
-  if (lane_id() == 0) red[threadIdx.x >> 6] = best;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 4; ++i) best = red[i] < best ? red[i] : best;
-    if (best != ~0ull) atomicMin(&st->key, best);
-  }
+  return best;  // the wave's minimum in every lane
 }
 
 // The decision at the subtree root the scan found (map_first_of_two's loop body): which of the tied
 // points A, B the nearest-neighbour search for q visits first is settled at their lowest common
-// ancestor; otherwise the region shrinks to the side both lie on.
-__global__ void k_region_step(MapView m, MapTieWalk *st) {
-  if (threadIdx.x != 0 || st->done) return;
-  const unsigned long long key = st->key;
-  st->key = ~0ull;
+// ancestor; otherwise the region shrinks to the side both lie on.  One thread.
+__device__ void region_step(const MapView &m, MapTieWalk *st, unsigned long long key) {
   st->steps++;
   if (key == ~0ull) {  // empty region: cannot happen (A and B are inside); reported as unresolved
     st->done = 2;
@@ -1597,6 +1600,57 @@ __global__ void k_region_step(MapView m, MapTieWalk *st) {
     st->lo[axis] = split;
   st->cur_perm = cperm;
   st->axis = axis ^ 1;
+}
+
+// One step with the whole grid scanning (the top of the tree: regions of millions of points); the
+// workgroup that finishes last takes the decision.
+__global__ __launch_bounds__(256) void k_region_walk_grid(MapView m, MapTieWalk *st) {
+  if (st->done) return;  // (every workgroup reads the same value: only the last one of a launch writes it)
+  const WalkRegion g{st->lo[0], st->hi[0], st->lo[1], st->hi[1], st->cur_perm};
+  __shared__ unsigned long long red[4];
+  __shared__ int last;
+  const unsigned long long wbest = region_scan_rows(m, g, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, 256);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = wbest;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long best = red[0];
+    for (int i = 1; i < 4; ++i) best = red[i] < best ? red[i] : best;
+    if (best != ~0ull) atomicMin(&st->key, best);
+    __threadfence();
+    last = atomicAdd(&st->ticket, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long key = __hip_atomic_load(&st->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st->key = ~0ull;
+    st->ticket = 0;
+    region_step(m, st, key);
+  }
+}
+
+// The rest of the walk in one workgroup: after a dozen halvings the region holds a few thousand
+// points, and a step is a scan of a few cell rows.
+__global__ __launch_bounds__(1024) void k_region_walk_block(MapView m, MapTieWalk *st, int max_steps) {
+  __shared__ unsigned long long red[16];
+  __shared__ int done_s;
+  for (int it = 0; it < max_steps; ++it) {
+    if (threadIdx.x == 0) done_s = st->done;
+    __syncthreads();
+    if (done_s) return;
+    const WalkRegion g{st->lo[0], st->hi[0], st->lo[1], st->hi[1], st->cur_perm};
+    // a wave per cell row, its lanes along the row
+    const unsigned long long wbest = region_scan_rows(m, g, (int)(threadIdx.x >> 6), 16, (int)lane_id(), WAVE);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = wbest;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long best = red[0];
+      for (int i = 1; i < 16; ++i) best = red[i] < best ? red[i] : best;
+      region_step(m, st, best);
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
 }
 
 // LDS per wave of the edge kernels: x, y, z tile + hit buffer (4 * TCAP floats = 8 KB); the hit
@@ -2027,7 +2081,7 @@ void launch_init_bounds(unsigned *d_bounds, hipStream_t s) {
   hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, d_bounds);
 }
 void launch_bounds(const float *d_xyz, size_t n, size_t stride, unsigned *d_bounds, hipStream_t s) {
-  hipLaunchKernelGGL(k_bounds, dim3(blocks_for(n, 256, 2048)), dim3(256), 0, s, d_xyz, n, stride,
+  hipLaunchKernelGGL(k_bounds, dim3(blocks_for(n, 256, 1024)), dim3(256), 0, s, d_xyz, n, stride,
                      d_bounds);
 }
 void launch_cell_count(const float *d_xyz, size_t n, size_t stride, float x0, float y0, float inv_g,
@@ -2090,13 +2144,13 @@ void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieS
                          hipStream_t s) {
   hipLaunchKernelGGL(k_map_tied_set, dim3(1), dim3(WAVE), 0, s, m, qx, qy, r0, d_out);
 }
-void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int steps, hipStream_t s) {
-  // one block per cell row of the region, at most 2048 blocks (rows are strided beyond that)
-  const int rows = m.H < 2048 ? m.H : 2048;
-  for (int k = 0; k < steps; ++k) {
-    hipLaunchKernelGGL(k_region_min_perm, dim3(rows), dim3(256), 0, s, m, d_state);
-    hipLaunchKernelGGL(k_region_step, dim3(1), dim3(64), 0, s, m, d_state);
-  }
+void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int grid_steps, int block_steps, hipStream_t s) {
+  // the top of the tree with the whole grid (cell rows strided over the workgroups), the rest in one
+  // workgroup
+  const int rows = m.H < 256 ? m.H : 256;
+  for (int k = 0; k < grid_steps; ++k)
+    hipLaunchKernelGGL(k_region_walk_grid, dim3(rows), dim3(256), 0, s, m, d_state);
+  if (block_steps > 0) hipLaunchKernelGGL(k_region_walk_block, dim3(1), dim3(1024), 0, s, m, d_state, block_steps);
 }
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,
                        const int *n_acc, const float *sx, const float *sy, const float *sz,

@@ -71,7 +71,8 @@ class TrgStats(C.Structure):
         ("map_nn_ties", C.c_uint64),
         ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double),
         ("map_nn_resolved", C.c_uint64), ("map_nn_unresolved", C.c_uint64),
-        ("bfs_tie_fixups", C.c_uint64), ("bytes_spec_created", C.c_uint64)]
+        ("bfs_tie_fixups", C.c_uint64), ("bytes_spec_created", C.c_uint64),
+        ("ms_rare_events", C.c_double)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
