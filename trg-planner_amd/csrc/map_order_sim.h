@@ -27,6 +27,7 @@ class MapOrderSim {
     buckets_ = 1;
     policy_ = std::__detail::_Prime_rehash_policy();
     order_.clear();
+    size_ = 0;
     rev_ = false;
   }
   // adopt the bucket state of a real map (its elements are NOT copied; call clear()/fill next)
@@ -38,40 +39,67 @@ class MapOrderSim {
     // floor(bucket_count * max_load_factor)
     if (buckets_ > 1) policy_._M_next_bkt(buckets_);  // sets _M_next_resize for this count
     order_.clear();
+    size_ = 0;
     rev_ = false;
   }
   // unordered_map::clear(): elements go, bucket array and policy stay
   void clear() {
     order_.clear();
+    size_ = 0;
     rev_ = false;
   }
   // nodes[key] = ... for the next dense key (must equal size())
-  void insert_next() {
-    const std::size_t key = order_.size();
-    const auto r = policy_._M_need_rehash(buckets_, order_.size(), 1);
-    if (r.first) {
-      buckets_ = r.second;
-      rev_ = !rev_;  // _M_rehash_aux: every element re-inserted at the front
-    }
-    if (rev_) {
-      order_.push_back((int)key);
-    } else {
-      order_.push_front((int)key);
-    }
-  }
+  void insert_next() { fill(1); }
+  // the next n dense keys.  The policy is asked only where the real container asks with an effect
+  // (_M_need_rehash returns at once while size + 1 <= _M_next_resize), so a fill costs one call per
+  // rehash, and the keys between two rehashes are kept as one run.
   void fill(std::size_t n) {
-    for (std::size_t i = 0; i < n; ++i) insert_next();
+    const std::size_t target = size_ + n;
+    while (size_ < target) {
+      if (size_ + 1 > policy_._M_next_resize) {
+        const auto r = policy_._M_need_rehash(buckets_, size_, 1);
+        if (r.first) {
+          buckets_ = r.second;
+          rev_ = !rev_;  // _M_rehash_aux: every element re-inserted at the front
+        }
+      }
+      // keys [size_, end) arrive without a further rehash
+      std::size_t end = policy_._M_next_resize > size_ ? policy_._M_next_resize : size_ + 1;
+      if (end > target) end = target;
+      const Run run{(int)size_, (int)end, !rev_};
+      if (rev_) {
+        if (!order_.empty() && !order_.back().front && order_.back().hi == run.lo)
+          order_.back().hi = run.hi;
+        else
+          order_.push_back(run);
+      } else {
+        if (!order_.empty() && order_.front().front && order_.front().hi == run.lo)
+          order_.front().hi = run.hi;
+        else
+          order_.push_front(run);
+      }
+      size_ = end;
+    }
   }
-  std::size_t size() const { return order_.size(); }
+  std::size_t size() const { return size_; }
   std::size_t bucket_count() const { return buckets_; }
   // keys in iteration order (begin() .. end())
   void iteration_order(std::vector<int> &out) const {
     out.clear();
-    out.reserve(order_.size());
+    out.reserve(size_);
+    // the element list: runs inserted at the front read newest first, runs appended at the back
+    // oldest first; after an odd number of rehashes the whole list is read backwards
+    auto emit = [&](const Run &r, bool backwards) {
+      const bool descending = r.front != backwards;
+      if (descending)
+        for (int k = r.hi - 1; k >= r.lo; --k) out.push_back(k);
+      else
+        for (int k = r.lo; k < r.hi; ++k) out.push_back(k);
+    };
     if (rev_) {
-      for (auto it = order_.rbegin(); it != order_.rend(); ++it) out.push_back(*it);
+      for (auto it = order_.rbegin(); it != order_.rend(); ++it) emit(*it, true);
     } else {
-      for (int k : order_) out.push_back(k);
+      for (const Run &r : order_) emit(r, false);
     }
   }
   // `*this = other` of the real containers: bucket count, policy state and element order are
@@ -79,9 +107,14 @@ class MapOrderSim {
   void assign_from(const MapOrderSim &o) { *this = o; }
 
  private:
+  struct Run {  // keys [lo, hi) inserted without a rehash in between; front: each went to the list's front
+    int lo, hi;
+    bool front;
+  };
   std::size_t buckets_ = 1;
   std::__detail::_Prime_rehash_policy policy_;
-  std::deque<int> order_;
+  std::deque<Run> order_;
+  std::size_t size_ = 0;
   bool rev_ = false;
 };
 

@@ -280,10 +280,12 @@ void launch_calls_select(const FinDev &F, const BfsDev &B, long long c0, long lo
                          int *flag, int *off, int *scan_tmp, int *list, unsigned long long *total,
                          hipStream_t s);
 void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
-void launch_fin_scatter_sort(const FinDev &F, const BfsDev &B, long long ncalls, int V, hipStream_t s);
-void launch_fin_clean(const FinDev &F, const BfsDev &B, const int *new2old, const int *old2new, int Vn,
-                      int *deg_new, int *rowptr_new, int *scan_tmp, int *col, float *w, float *dist,
-                      float *xyz, int *state, hipStream_t s);
+void launch_fin_scatter(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
+void launch_fin_rowsort(const FinDev &F, int V, hipStream_t s);
+void launch_fin_clean(const FinDev &F, const BfsDev &B, const int *map_order, int V, int *keep_flag,
+                      int *keep_pos, int *new2old, int *old2new, int *deg_new, int *rowptr_new,
+                      int *scan_tmp, int *col, float *w, float *dist, float *xyz, int *state,
+                      hipStream_t s);
 
 // ---- tile-boundary stitch of the tiled build (trg_stitch.inc) ----------------------------------------
 struct StitchRec {  // a boundary node: local id and position (16 bytes; layout of TrgBoundaryRec)
