@@ -150,9 +150,7 @@ enum : int {
   BFS_CTR_NMAPTIE = 6 /* and 7: one list per level parity */,
   BFS_CTR_NUNC1 = 8,  // uncertain gates of odd levels (the next level is expanded while the host
                       // still looks at this one)
-  // statistics of the level just committed (k_level_commit)
-  BFS_CTR_LDRAWS = 9, BFS_CTR_LSAMPLES = 10, BFS_CTR_LHITS_S = 11, BFS_CTR_LHITS_E = 12,
-  BFS_CTR_LHITS_NEW = 13,  // of LHITS_E: the parent edges of the nodes the level created
+  // (9..13 spare)
   BFS_CTR_NUNC2 = 14,      // uncertain gates of the deferred evaluations (third list)
   BFS_CTR_COUNT = 16
 };
@@ -160,6 +158,8 @@ enum : int {
   BFS_ERR_GRID_OVERFLOW = 1, BFS_ERR_NB_OVERFLOW = 2, BFS_ERR_VCAP = 4, BFS_ERR_TIE = 8,
   BFS_ERR_HASH = 16, BFS_ERR_LEVEL_TOO_BIG = 32, BFS_ERR_CLEAN = 64,
   BFS_ERR_STALL = 128,  // k_level_resolve's bounded wait ran out: the level is replayed on the host
+  BFS_ERR_LOOKBACK = 512,  // the commit's look-back scan ran out of polls (another process on the card): the
+                           // level's numbering is void, the whole build is redone by the host replay
   BFS_ERR_TIE_CLS = 256 // a sample's nearest PRE-LEVEL node was not unique (k_level_sample; the slot
                         // carries SLOT_TIE): the host picks the reference's winner, resolve + commit rerun
 };
@@ -223,7 +223,9 @@ struct BfsDev {
   int *c_outcome;   // per slot: resolve outcome (polled across workgroups)
   HashEnt *lv_hash;
   int ht_size;
-  int *blk_tot;     // per RW-slot group: created | valid << 16 (k_level_resolve -> k_level_commit)
+  unsigned long long *wg_state;  // per resolve workgroup: epoch | state | created | valid (look-back scan of the commit)
+  int4 *nexp;       // per expanded node: accepted | candidates << 8, draws, disc hits, speculative-edge hits
+  int *nhits;       // per created node: map points inside its parent edge's queries
   // deferred edge evaluation scratch
   float *mid;
   // uncertain slope gates for the host (2 x BFS_UNC_CAP, by level parity)
@@ -234,10 +236,10 @@ struct BfsDev {
   // call log (one record per sample slot, in program order)
   int *call_n1, *call_n2, *call_status;
   float *call_w, *call_dist;
-  int *newid_of_call;  // node id created by call number i (set by k_level_commit)
+  int *newid_of_call;  // node id created by call number i (set by the commit in k_level_resolve)
   // counters
   int *ctrs;
-  int *host_ctrs;      // pinned host copy of ctrs + stamp, written by k_level_commit (may be null)
+  int *host_ctrs;      // pinned host copy of ctrs + stamp, written by the next level's k_level_sample (may be null)
   unsigned long long *stats64;  // [6]: longest resolve wait; [8..13]: expand phase cycles (profiling)
 };
 
@@ -267,8 +269,10 @@ void launch_level_expand(const MapView &m, QueryParams p, const float *cos_t, co
 // whether the level kernels can serve these parameters (window of the node grid, sample count)
 bool level_kernels_support(const QueryParams &p, float grid_cell);
 void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int new_state,
-                                 long long call_base, int V0, int tag, hipStream_t s,
-                                 bool stall_test = false);
+                                 long long call_base, int V0, int tag, int epoch, hipStream_t s,
+                                 bool stall_test);
+// sums of the per-node expansion statistics into out[0..5] (added to what is there)
+void launch_bfs_stats(const BfsDev &B, int V, unsigned long long *out, hipStream_t s);
 // weights of the edges to the nodes [1, V) the BFS created (covariance -> SVD -> weight)
 void launch_node_weights(const BfsDev &B, int V, hipStream_t s);
 // deferred wireEdge evaluations of the calls list[0..count) (count_dev != nullptr: count is an upper
