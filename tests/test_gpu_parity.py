@@ -12,6 +12,8 @@ from conftest import assert_graph_equal
 pytestmark = pytest.mark.gpu
 
 WEIGHT_TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 for float risk"
+MOUNTAIN_S16 = dict(expand_dist=0.6, robot_size=0.3, height_threshold=0.16, collision_threshold=0.1,
+                    update_collision_threshold=0.5, safety_factor=3.0, goal_tolerance=0.8, sample_num=16)
 
 
 def _engine(params, **kw):
@@ -359,6 +361,23 @@ def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
     c = o.counters()
     assert st["trials"] == c["trials"] and st["samples"] == c["samples"]
     assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
+
+
+def test_statistics_equal_across_repeated_builds(mountain_small):
+    """The expansion statistics are summed on the device after the level loop; the host must read them
+    only when that kernel has finished (three builds on one engine give the same numbers)."""
+    e = _engine(dict(MOUNTAIN_S16))
+    e.set_sampler(7, 16)
+    keys = ("trials", "samples", "created_nodes", "invalid_nodes", "edge_evals_gpu",
+            "bytes_sample_kernel", "bytes_spec_kernel", "bytes_spec_created", "bytes_edge_kernel")
+    seen = []
+    for _ in range(3):
+        e.set_global_map(mountain_small)
+        e.init_graph([15.0, 15.0, 0.0])
+        st = e.stats()
+        seen.append(tuple(st[k] for k in keys))
+    assert seen[0] == seen[1] == seen[2], seen
+    assert seen[0][0] > 0 and seen[0][5] > 0
 
 
 def test_device_build_is_deterministic(oa, mountain_gentle):

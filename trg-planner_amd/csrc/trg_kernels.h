@@ -186,11 +186,13 @@ struct alignas(16) SlotRec {
   int hits;        //   map points inside the edge's query radii (instrumentation)
 };
 enum : int { SLOT_CLS_MASK = 0xFF, SLOT_TIE = 0x100 };
-struct alignas(16) NodeRec {  // per queued node of a level, 32 bytes
+struct alignas(16) NodeRec {  // per queued node of a level, 48 bytes
   int n_acc, n_draws;         // accepted samples, draws made
   int hits_sample, hits_spec; // map points inside its sampling discs / speculative-edge queries
   unsigned cand_lo, cand_hi;  // bit j: accepted sample j is a candidate
   int pad[2];
+  float px, py, pz;           // the node itself (k_level_spec: its speculative edges start here)
+  int pad2;
 };
 struct alignas(16) HashEnt {  // candidate hash of a level: node-grid cell -> candidate
   unsigned long long tagcell; // level tag << 32 | cell; entries of other levels count as empty
@@ -216,6 +218,7 @@ struct BfsDev {
   int GW, GH;
   // frontier ping-pong
   int *front_cur, *front_next;
+  float2 *fxy_cur, *fxy_next;  // their positions (the sampling workgroup starts from here)
   int fcap;
   // level records (two sets, by level parity)
   NodeRec *node_rec;
