@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
     k = re.sub(r"\(.*", "", k).split("::")[-1].strip()
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
 rows.sort()
-commits = [i for i, r in enumerate(rows) if r[2] == "k_level_commit"]
+commits = [i for i, r in enumerate(rows) if r[2] == "k_level_resolve"]  # (the last kernel of a level)
 # builds are separated by the index kernels; take the last build's commits
 last = [i for i in commits if i > max([j for j, r in enumerate(rows) if r[2] == "k_bounds"] or [0])]
 mid = last[len(last) // 2]
