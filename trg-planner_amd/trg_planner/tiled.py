@@ -22,6 +22,8 @@ tiled CPU oracle and the CPU gloo test.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 try:  # the exchanges ride on torch.distributed; torch's ROCm libraries must load before the engine's
@@ -73,8 +75,9 @@ def allgatherv_t(t, dist=None):
     (device tensors over RCCL, host tensors over gloo): counts first, then padded payloads (RCCL has
     no native allgatherv).  Returns (concatenation in rank order, counts list)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return t, [int(t.shape[0])]
+    if dist is None or not dist.is_initialized() or (
+            dist.get_world_size() == 1 and not os.environ.get("TRG_FORCE_COLLECTIVES")):
+        return t, [int(t.shape[0])]  # (TRG_FORCE_COLLECTIVES: tests run the exchange with one rank)
     world = dist.get_world_size()
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]

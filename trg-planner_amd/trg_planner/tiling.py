@@ -32,7 +32,9 @@ def tile_of_rank(rank, world_size, nx, ny, spacing=0.1):
 
 def reduce_throughput(items, seconds, dist=None, device=None):
     """Whole-job (sum of items, max of seconds) over all ranks; plain values when not distributed."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    import os
+    if dist is None or not dist.is_initialized() or (
+            dist.get_world_size() == 1 and not os.environ.get("TRG_FORCE_COLLECTIVES")):
         return float(items), float(seconds)
     import torch
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
