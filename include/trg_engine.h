@@ -260,7 +260,8 @@ TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size
  * "debug_spec_bound" = n (cap the speculative next-level sampling launch at n nodes -> top-up
  * launches), "debug_fallback_level" = n (the device BFS declines at level n -> whole-build host
  * replay), "debug_stall_level" = n (k_bfs_resolve leaves one candidate of level n undecided ->
- * BFS_ERR_STALL -> the level is taken back and replayed on the host). */
+ * BFS_ERR_STALL -> the level is taken back and replayed on the host), "debug_lookback_level" = n (one
+ * workgroup's commit look-back gives up at level n -> BFS_ERR_LOOKBACK -> whole-build host replay). */
 TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value);
 /* Tiled builds (multi-GPU; an extension, not a reference interface): restrict
  * node creation to the core region [x0,x1) x [y0,y1) -- a sample outside it counts as a rejected

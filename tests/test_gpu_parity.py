@@ -363,6 +363,25 @@ def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
     assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
 
 
+def test_failed_commit_lookback_falls_back_to_the_host_replay(oa, mountain_small):
+    """The commit's look-back scan waits for lower workgroups with a bound; when it runs out (another
+    process's kernels on the card) the level's numbering is void and the whole build is redone by the
+    host replay.  The hook makes one workgroup of level 7 give up."""
+    prm = dict(oa.MOUNTAIN, sample_num=10)
+    e = _engine(prm)
+    e.set_sampler(21, 16)
+    e.set_option("debug_lookback_level", 7)
+    e.set_global_map(mountain_small)
+    e.init_graph([15.0, 15.0, 0.0])
+    st = e.stats()
+    assert st["bfs_fallbacks"] == 1 and "look-back" in e.fallback_reason, (st, e.fallback_reason)
+    o = oa.Oracle(**prm)
+    o.set_sampler(21, 0, 16)
+    o.set_global_map(mountain_small)
+    assert o.init_graph([15.0, 15.0, 0.0])
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
+
+
 def test_statistics_equal_across_repeated_builds(mountain_small):
     """The expansion statistics are summed on the device after the level loop; the host must read them
     only when that kernel has finished (three builds on one engine give the same numbers)."""

@@ -348,6 +348,7 @@ struct TrgEngine {
   int debug_spec_bound = 0;      // test hook: cap the speculative sampling launch at n nodes
   int debug_fallback_level = -1; // test hook: the device BFS declines at this level
   bool tie_inplace = true;       // node-distance ties settled slot by slot on the committed level (off: host level replay)
+  int debug_lookback_level = -1; // test hook: one workgroup's commit look-back gives up at this level
   int debug_stall_level = -1;    // test hook: k_bfs_resolve leaves one candidate of this level undecided
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
@@ -1704,7 +1705,8 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     e->stats.bytes_index_build = keep.bytes_index_build;
     e->stats.ms_set_map_total = keep.ms_set_map_total;
   }
-  HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
+  // (in the main stream: it is non-blocking, a plain memset would not be ordered with the kernels)
+  HIPCHK(e, hipMemsetAsync(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters), e->s_main));
   e->lv_hits_sample = e->lv_hits_spec = 0;
   const bool want_device = !e->step3 && e->use_device_bfs;
   if (!want_device) ensure_real_map(e);
@@ -1759,6 +1761,10 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     // the device path declined (capacity, or an exact fp32 tie whose winner depends on the
     // reference kd-tree's shape): redo the build with the host replay, which handles those
     e->stats.bfs_fallbacks++;
+    // (kernels of the abandoned attempt may still be in flight: the streams do not synchronise with
+    // plain copies / memsets)
+    HIPCHK(e, hipStreamSynchronize(e->s_main));
+    HIPCHK(e, hipStreamSynchronize(e->s_edge));
     HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
     e->lv_hits_sample = e->lv_hits_spec = 0;
     e->nodes_sim = sim_before;
@@ -1812,6 +1818,10 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_stall_level") {
     e->debug_stall_level = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "debug_lookback_level") {
+    e->debug_lookback_level = atoi(v.c_str());
     return TRG_OK;
   }
   if (k == "tie_inplace") {

@@ -273,7 +273,7 @@ void launch_level_expand(const MapView &m, QueryParams p, const float *cos_t, co
 bool level_kernels_support(const QueryParams &p, float grid_cell);
 void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int new_state,
                                  long long call_base, int V0, int tag, int epoch, hipStream_t s,
-                                 bool stall_test);
+                                 int stall_test);  // 0; test hooks: 1 a candidate stays undecided, 2 a look-back gives up
 // sums of the per-node expansion statistics into out[0..5] (added to what is there)
 void launch_bfs_stats(const BfsDev &B, int V, unsigned long long *out, hipStream_t s);
 // weights of the edges to the nodes [1, V) the BFS created (covariance -> SVD -> weight)
