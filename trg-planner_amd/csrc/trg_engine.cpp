@@ -48,6 +48,12 @@ inline double ms_since(Clock::time_point t0) {
 }
 inline float norm2f(float dx, float dy) { return sqrtf(dx * dx + dy * dy); }
 
+struct IndexScratch {  // temporaries of build_index, grown on demand
+  int *cell_of = nullptr, *rank = nullptr, *counts = nullptr, *tmp = nullptr;
+  void *aos = nullptr;
+  size_t cap_pts = 0, cap_cells = 0;
+};
+
 struct DevMap {
   size_t n = 0;
   float *x = nullptr, *y = nullptr, *z = nullptr;
@@ -275,6 +281,7 @@ struct TrgEngine {
 
   hipStream_t s_main = nullptr, s_edge = nullptr;
   DevMap gmap, lmap;
+  IndexScratch idx_scratch;
   DeviceCounters *d_ctr = nullptr;
   unsigned *d_bounds = nullptr;
 
@@ -488,16 +495,36 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
     HIPCHK(e, hipMalloc((void **)&m.cell_start, (ncell + 1) * sizeof(int)));
     m.cap_cells = ncell + 1;
   }
-  int *d_cell_of = nullptr, *d_rank = nullptr, *d_counts = nullptr, *d_tmp = nullptr;
-  HIPCHK(e, hipMalloc((void **)&d_cell_of, n * sizeof(int)));
-  HIPCHK(e, hipMalloc((void **)&d_rank, n * sizeof(int)));
-  HIPCHK(e, hipMalloc((void **)&d_counts, ncell * sizeof(int)));
-  HIPCHK(e, hipMalloc((void **)&d_tmp, (ncell / 2048 + 4) * sizeof(int)));
+  // scratch of the build, kept with the engine (allocating and freeing 240 MB per build costs as much as
+  // a kernel of it)
+  IndexScratch &sc = e->idx_scratch;
+  if (sc.cap_pts < n) {
+    if (sc.cell_of) (void)hipFree(sc.cell_of);
+    if (sc.rank) (void)hipFree(sc.rank);
+    if (sc.aos) (void)hipFree(sc.aos);
+    sc.cell_of = sc.rank = nullptr;
+    sc.aos = nullptr;
+    sc.cap_pts = 0;
+    HIPCHK(e, hipMalloc((void **)&sc.cell_of, n * sizeof(int)));
+    HIPCHK(e, hipMalloc((void **)&sc.rank, n * sizeof(int)));
+    HIPCHK(e, hipMalloc((void **)&sc.aos, n * 16));
+    sc.cap_pts = n;
+  }
+  if (sc.cap_cells < ncell) {
+    if (sc.counts) (void)hipFree(sc.counts);
+    if (sc.tmp) (void)hipFree(sc.tmp);
+    sc.counts = sc.tmp = nullptr;
+    sc.cap_cells = 0;
+    HIPCHK(e, hipMalloc((void **)&sc.counts, ncell * sizeof(int)));
+    HIPCHK(e, hipMalloc((void **)&sc.tmp, (ncell / 2048 + 4) * sizeof(int)));
+    sc.cap_cells = ncell;
+  }
+  int *d_cell_of = sc.cell_of, *d_rank = sc.rank, *d_counts = sc.counts, *d_tmp = sc.tmp;
   HIPCHK(e, hipMemsetAsync(d_counts, 0, ncell * sizeof(int), s));
   launch_cell_count(d_xyz, n, stride, x0, y0, inv_g, W, H, d_cell_of, d_rank, d_counts, s);
   launch_exclusive_scan(d_counts, m.cell_start, (int)ncell, d_tmp, s);
-  launch_scatter(d_xyz, n, stride, d_cell_of, d_rank, m.cell_start, m.x, m.y, m.z, m.perm, s);
-  launch_cell_sort((int)ncell, m.cell_start, m.x, m.y, m.z, m.perm, s);
+  launch_scatter_sort_aos(d_xyz, n, stride, d_cell_of, d_rank, (int)ncell, m.cell_start, sc.aos, m.x, m.y, m.z,
+                          m.perm, s);
   HIPCHK(e, hipEventRecord(ev1, s));
   HIPCHK(e, hipStreamSynchronize(s));
   HIPCHK(e, hipGetLastError());
@@ -505,10 +532,6 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
   (void)hipEventElapsedTime(&ms, ev0, ev1);
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
-  (void)hipFree(d_cell_of);
-  (void)hipFree(d_rank);
-  (void)hipFree(d_counts);
-  (void)hipFree(d_tmp);
 
   m.n = n;
   m.g = g;
@@ -1618,6 +1641,9 @@ void trg_engine_destroy(TrgEngine *e) {
     if (e->d_sin) (void)hipFree(e->d_sin);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->d_bounds) (void)hipFree(e->d_bounds);
+    for (void *p : {(void *)e->idx_scratch.cell_of, (void *)e->idx_scratch.rank, (void *)e->idx_scratch.counts,
+                    (void *)e->idx_scratch.tmp, e->idx_scratch.aos})
+      if (p) (void)hipFree(p);
     if (e->s_main) (void)hipStreamDestroy(e->s_main);
     if (e->s_edge) (void)hipStreamDestroy(e->s_edge);
   }

@@ -91,6 +91,10 @@ void launch_scatter(const float *d_xyz, size_t n, size_t stride, const int *d_ce
                     int *perm, hipStream_t s);
 void launch_cell_sort(int ncell, const int *d_cell_start, float *x, float *y, float *z, int *perm,
                       hipStream_t s);
+// scatter + per-cell sort through a scratch array of n 16-byte records (one store per point)
+void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
+                             const int *d_rank, int ncell, const int *d_cell_start, void *d_aos, float *x,
+                             float *y, float *z, int *perm, hipStream_t s);
 
 // ---- queries -----------------------------------------------------------------------------------
 void launch_probe_collision(const MapView &m, QueryParams p, float threshold, const float *d_xy,

@@ -1372,6 +1372,20 @@ __global__ __launch_bounds__(256) void k_scatter(const float *xyz, size_t n, siz
   }
 }
 
+// The same scatter with ONE 16-byte store per point (x, y, z, original index) into a scratch array:
+// the destinations are random (the cloud arrives shuffled), and a random 4-byte store costs a memory
+// transaction just like a 16-byte one -- four of them per point made k_scatter the longest kernel
+// of the index build.  k_cell_sort_aos turns the records into the SoA arrays the queries read.
+__global__ __launch_bounds__(256) void k_scatter_aos(const float *xyz, size_t n, size_t stride,
+                                                     const int *cell_of, const int *rank,
+                                                     const int *cell_start, float4 *aos) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int dst = cell_start[cell_of[i]] + rank[i];
+    aos[dst] = make_float4(xyz[i * stride], xyz[i * stride + 1], xyz[i * stride + 2], __int_as_float((int)i));
+  }
+}
+
 // The atomic rank above is arrival order; sorting every cell by original index makes the index
 // (and therefore every fp64 accumulation order downstream) independent of scheduling.
 constexpr int CSORT_CAP = 3072;  // points of 256 consecutive cells staged in LDS (48 KB)
@@ -1416,6 +1430,47 @@ __global__ __launch_bounds__(256) void k_cell_sort(int ncell, const int *cell_st
     ly[i] = y[p0 + i];
     lz[i] = z[p0 + i];
     lp[i] = perm[p0 + i];
+  }
+  __syncthreads();
+  if (c < ncell) cell_insertion_sort(lx, ly, lz, lp, cell_start[c] - p0, cell_start[c + 1] - p0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    x[p0 + i] = lx[i];
+    y[p0 + i] = ly[i];
+    z[p0 + i] = lz[i];
+    perm[p0 + i] = lp[i];
+  }
+}
+
+// k_cell_sort reading the 16-byte records k_scatter_aos left and writing the SoA arrays
+__global__ __launch_bounds__(256) void k_cell_sort_aos(int ncell, const int *cell_start, const float4 *aos,
+                                                       float *x, float *y, float *z, int *perm) {
+  __shared__ float lx[CSORT_CAP], ly[CSORT_CAP], lz[CSORT_CAP];
+  __shared__ int lp[CSORT_CAP];
+  const int c0 = blockIdx.x * blockDim.x;
+  const int c = c0 + threadIdx.x;
+  const int p0 = cell_start[c0], p1 = cell_start[min(c0 + (int)blockDim.x, ncell)];
+  const int n = p1 - p0;
+  if (n > CSORT_CAP) {  // (a range too long for LDS: unpack in place, sort in global memory)
+    if (c < ncell) {
+      const int s0 = cell_start[c], s1 = cell_start[c + 1];
+      for (int i = s0; i < s1; ++i) {
+        const float4 r = aos[i];
+        x[i] = r.x;
+        y[i] = r.y;
+        z[i] = r.z;
+        perm[i] = __float_as_int(r.w);
+      }
+      cell_insertion_sort(x, y, z, perm, s0, s1);
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float4 r = aos[p0 + i];
+    lx[i] = r.x;
+    ly[i] = r.y;
+    lz[i] = r.z;
+    lp[i] = __float_as_int(r.w);
   }
   __syncthreads();
   if (c < ncell) cell_insertion_sort(lx, ly, lz, lp, cell_start[c] - p0, cell_start[c + 1] - p0);
@@ -2100,6 +2155,14 @@ void launch_scatter(const float *d_xyz, size_t n, size_t stride, const int *d_ce
                     int *perm, hipStream_t s) {
   hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, d_xyz, n, stride,
                      d_cell_of, d_rank, d_cell_start, x, y, z, perm);
+}
+void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
+                             const int *d_rank, int ncell, const int *d_cell_start, void *d_aos, float *x,
+                             float *y, float *z, int *perm, hipStream_t s) {
+  hipLaunchKernelGGL(k_scatter_aos, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, d_xyz, n, stride,
+                     d_cell_of, d_rank, d_cell_start, (float4 *)d_aos);
+  hipLaunchKernelGGL(k_cell_sort_aos, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d_cell_start,
+                     (const float4 *)d_aos, x, y, z, perm);
 }
 void launch_cell_sort(int ncell, const int *d_cell_start, float *x, float *y, float *z, int *perm,
                       hipStream_t s) {
