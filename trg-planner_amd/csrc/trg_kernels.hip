@@ -1483,7 +1483,10 @@ __global__ __launch_bounds__(256) void k_cell_sort_aos(int ncell, const int *cel
   }
 }
 
-constexpr int QW = 4;  // waves (= queries) per block in the probe / edge kernels
+#ifndef TRG_QW
+#define TRG_QW 4
+#endif
+constexpr int QW = TRG_QW;  // waves (= queries) per block in the probe / edge kernels
 
 __global__ __launch_bounds__(QW *WAVE) void k_probe_collision(MapView m, QueryParams p,
                                                               float threshold, const float *xy,
