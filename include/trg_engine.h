@@ -250,8 +250,9 @@ TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size
 /* ---- options ----------------------------------------------------------------------------------- */
 /* "replay" = "device" (default: BFS, dedupe and CSR on the GPU when expandGraph's step 3 is off,
  * trg.cpp:429) | "host" (sequential replay on the host, the only mode for step-3 configs);
- * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot); "defer_overlap" = "0" | "1"
- * (device BFS: deferred wireEdge evaluations pipelined behind the level loop on a second stream);
+ * "keep_preclean" = "0" | "1" (keep the TRG_KIND_PRECLEAN snapshot); "defer_overlap" = "1" | "0" | "2"
+ * (device BFS: deferred wireEdge evaluations pipelined behind the level loop on a second stream, one
+ * batch per level -- default; 0: after the loop; 2: only pair-table inserts and selection beside the loop);
  * "tie_inplace" = "1" | "0" (device BFS: a nearest-node distance tie is settled for the affected slot alone on
  * the committed level -- off: the whole level is replayed on the host).  All modes give identical
  * graphs; the env var TRG_REPLAY=host sets the default.  Test hooks (never change results):

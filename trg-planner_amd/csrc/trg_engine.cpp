@@ -346,7 +346,8 @@ struct TrgEngine {
   StitchBufs *stitch = nullptr;
   bool keep_preclean = false;    // instrumentation: snapshot the graph before cleanGraph
   bool use_device_bfs = true;    // device-resident BFS when expandGraph's step 3 is disabled
-  bool defer_overlap = false;    // deferred edge evaluations pipelined behind the level loop on a 2nd stream
+  int defer_overlap = 1;         // 1: deferred edge evaluations pipelined behind the level loop on a 2nd stream;
+                                 // 2: only the pair-table inserts + first-of-pair selection run beside the loop
                                  // (measured: the loop loses more than the pipeline gains; kept as an option)
   bool pool_valid = true;        // e->edges mirrors csr_global
   bool host_grid_valid = true;   // e->grid holds the current node set
@@ -1839,7 +1840,7 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
     return TRG_OK;
   }
   if (k == "defer_overlap") {
-    e->defer_overlap = v != "0";
+    e->defer_overlap = atoi(v.c_str());
     return TRG_OK;
   }
   if (k == "debug_stall_level") {

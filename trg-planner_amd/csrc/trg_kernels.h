@@ -289,7 +289,7 @@ void launch_calls_eval(const MapView &m, QueryParams p, const BfsDev &B, const i
 void launch_first_insert(const FinDev &F, const BfsDev &B, long long c0, long long c1, hipStream_t s);
 void launch_calls_select(const FinDev &F, const BfsDev &B, long long c0, long long c1, int round,
                          int *flag, int *off, int *scan_tmp, int *list, unsigned long long *total,
-                         hipStream_t s);
+                         hipStream_t s, int *count_out = nullptr);
 void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
 void launch_fin_scatter(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
 void launch_fin_rowsort(const FinDev &F, int V, hipStream_t s);
