@@ -63,6 +63,11 @@ struct DevMap {
   float g = 0;
   float bounds[4] = {0, 0, 0, 0};
   bool valid = false;
+  // the top of the reference's insertion-built kd-tree over this map: its first points (original index
+  // < top_m), built lazily when a nearest-point tie has to be broken (map_first_of_two)
+  int top_m = 0;
+  std::vector<float> top_xy;
+  std::vector<int> top_left, top_right;
 };
 
 template <typename T>
@@ -280,6 +285,7 @@ struct TrgEngine {
   bool device_ok = false;
 
   hipStream_t s_main = nullptr, s_edge = nullptr;
+  hipStream_t s_aux = nullptr;  // rare-event work (nearest-point tie walks) beside whatever the main stream holds
   DevMap gmap, lmap;
   IndexScratch idx_scratch;
   DeviceCounters *d_ctr = nullptr;
@@ -552,6 +558,7 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
   m.view.H = H;
   m.view.n = (int)n;
   m.valid = true;
+  m.top_m = 0;  // (the top of the insertion tree is rebuilt on demand)
   if (&m == &e->gmap) {
     e->stats.map_points = n;
     e->stats.ms_index_build = ms;
@@ -711,9 +718,46 @@ TrgStatus ensure_tie_scratch(TrgEngine *e) {
 // walk (region scan + decision per tree level, ~30-50 levels on a 10 M-point map) runs on the device
 // without the host in between: the first steps (regions of millions of points) one grid-wide kernel
 // each, enqueued blindly, the rest inside a single workgroup; steps after the decision return at once.
-TrgStatus map_first_of_two(TrgEngine *e, const DevMap &m, float qx, float qy, const TiePoint &A,
+constexpr int MAP_TOP_POINTS = 8192;  // points of the host-side top of the map tree
+
+// The first MAP_TOP_POINTS points of the cloud, inserted like kd_insert does (kdtree.c:179-198: `<` goes
+// left, the axis alternates with the depth): the top of the reference's map tree, node k = cloud point k.
+TrgStatus ensure_map_top(TrgEngine *e, DevMap &m) {
+  if (m.top_m > 0) return TRG_OK;
+  const int M = (int)std::min<size_t>(m.n, MAP_TOP_POINTS);
+  float *d_xy = nullptr;
+  HIPCHK(e, hipMalloc((void **)&d_xy, (size_t)M * 2 * sizeof(float)));
+  launch_collect_first(m.view, M, d_xy, e->s_aux);
+  m.top_xy.resize((size_t)M * 2);
+  hipError_t he = hipMemcpyAsync(m.top_xy.data(), d_xy, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToHost, e->s_aux);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->s_aux);
+  (void)hipFree(d_xy);
+  if (he != hipSuccess) return e->fail(TRG_ERR_DEVICE, std::string("map top: ") + hipGetErrorString(he));
+  m.top_left.assign(M, -1);
+  m.top_right.assign(M, -1);
+  for (int k = 1; k < M; ++k) {
+    const float px = m.top_xy[2 * (size_t)k], py = m.top_xy[2 * (size_t)k + 1];
+    int cur = 0, axis = 0;
+    for (;;) {
+      const float split = axis ? m.top_xy[2 * (size_t)cur + 1] : m.top_xy[2 * (size_t)cur];
+      int &child = ((axis ? py : px) < split) ? m.top_left[cur] : m.top_right[cur];
+      if (child < 0) {
+        child = k;
+        break;
+      }
+      cur = child;
+      axis ^= 1;
+    }
+  }
+  m.top_m = M;
+  return TRG_OK;
+}
+
+TrgStatus map_first_of_two(TrgEngine *e, DevMap &m, float qx, float qy, const TiePoint &A,
                            const TiePoint &B, int *first) {
-  hipStream_t s = e->s_main;
+  hipStream_t s = e->s_aux;  // (the main stream is busy with the next level's speculative expansion)
+  TrgStatus st = ensure_map_top(e, m);
+  if (st != TRG_OK) return st;
   MapTieWalk w{};
   w.key = ~0ull;
   w.lo[0] = w.lo[1] = -INFINITY;
@@ -728,11 +772,47 @@ TrgStatus map_first_of_two(TrgEngine *e, const DevMap &m, float qx, float qy, co
   w.ay = A.y;
   w.bx = B.x;
   w.by = B.y;
+  // the common path of A and B through the top of the tree, on the host (the same decisions as
+  // region_step on the device, trg_kernels.hip)
+  {
+    int cur = 0;
+    for (;;) {
+      const float cx = m.top_xy[2 * (size_t)cur], cy = m.top_xy[2 * (size_t)cur + 1];
+      const int axis = w.axis;
+      const float split = axis ? cy : cx;
+      const float q = axis ? qy : qx;
+      const bool near_is_left = (q - split) <= 0;
+      const float ca = axis ? A.y : A.x, cb = axis ? B.y : B.x;
+      if (cur == A.perm || cur == B.perm) {
+        const bool cur_is_a = cur == A.perm;
+        const bool other_left = (cur_is_a ? cb : ca) < split;
+        const bool other_first = other_left == near_is_left;
+        *first = cur_is_a ? (other_first ? 1 : 0) : (other_first ? 0 : 1);
+        return TRG_OK;
+      }
+      const bool a_left = ca < split, b_left = cb < split;
+      if (a_left != b_left) {
+        *first = (a_left == near_is_left) ? 0 : 1;
+        return TRG_OK;
+      }
+      if (a_left)
+        w.hi[axis] = split;
+      else
+        w.lo[axis] = split;
+      w.cur_perm = cur;
+      w.axis = axis ^ 1;
+      w.steps++;
+      const int child = a_left ? m.top_left[cur] : m.top_right[cur];
+      if (child < 0) break;  // the subtree's root is a later point: the device goes on from this region
+      cur = child;
+    }
+  }
   *e->mt_walk_h = w;
   HIPCHK(e, hipMemcpyAsync(e->mt_walk_d, e->mt_walk_h, sizeof(MapTieWalk), hipMemcpyHostToDevice, s));
   for (int batch = 0; batch < 64; ++batch) {
-    // (12 halvings leave ~N / 4096 points; an unbalanced walk just spends longer in the one-workgroup kernel)
-    launch_map_tie_walk(m.view, e->mt_walk_d, batch == 0 ? 12 : 0, 64, s);
+    // what is left of the region after the top of the tree holds ~N / 8192 points: one workgroup walks it
+    // (a full-size region -- a map smaller than the top -- cannot get here)
+    launch_map_tie_walk(m.view, e->mt_walk_d, 0, 64, s);
     HIPCHK(e, hipMemcpyAsync(e->mt_walk_h, e->mt_walk_d, sizeof(MapTieWalk), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipStreamSynchronize(s));
     if (e->mt_walk_h->done == 1) {
@@ -745,10 +825,10 @@ TrgStatus map_first_of_two(TrgEngine *e, const DevMap &m, float qx, float qy, co
 }
 
 // z of the map point kd_nearest returns for (qx, qy), ties decided as the reference's tree does
-TrgStatus map_nn_exact(TrgEngine *e, const DevMap &m, float qx, float qy, float *z, bool *found) {
+TrgStatus map_nn_exact(TrgEngine *e, DevMap &m, float qx, float qy, float *z, bool *found) {
   TrgStatus st = ensure_tie_scratch(e);
   if (st != TRG_OK) return st;
-  hipStream_t s = e->s_main;
+  hipStream_t s = e->s_aux;  // (the map is read-only here; the main stream may hold speculative work)
   launch_map_tied_set(m.view, qx, qy, e->prm.robot_size, e->mt_set_d, s);
   HIPCHK(e, hipMemcpyAsync(e->mt_set_h, e->mt_set_d, sizeof(MapTieSet), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
@@ -1572,6 +1652,7 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
     } else {
       HIPCHK(e, hipStreamCreateWithPriority(&e->s_edge, hipStreamNonBlocking, pr_least));
     }
+    HIPCHK(e, hipStreamCreateWithFlags(&e->s_aux, hipStreamNonBlocking));
   }
   HIPCHK(e, hipMalloc((void **)&e->d_ctr, COUNTER_SHARDS * sizeof(DeviceCounters)));
   HIPCHK(e, hipMemset(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters)));
@@ -1647,6 +1728,7 @@ void trg_engine_destroy(TrgEngine *e) {
       if (p) (void)hipFree(p);
     if (e->s_main) (void)hipStreamDestroy(e->s_main);
     if (e->s_edge) (void)hipStreamDestroy(e->s_edge);
+    if (e->s_aux) (void)hipStreamDestroy(e->s_aux);
   }
   delete e;
 }

@@ -136,6 +136,8 @@ struct MapTieWalk {
   int ticket;              // workgroups of the current grid step that have finished
 };
 void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int grid_steps, int block_steps, hipStream_t s);
+// out_xy[2 * k], [2 * k + 1] = position of the point with original index k, for k < M
+void launch_collect_first(const MapView &m, int M, float *d_out_xy, hipStream_t s);
 // Speculative parent edges node -> sample for every accepted sample of a chunk:
 //   node_xyz[count*3]; slot = node*S + j evaluated iff j < n_acc[node]
 void launch_spec_edges(const MapView &m, QueryParams p, const float *node_xyz, int count,

@@ -1660,6 +1660,19 @@ __device__ void region_step(const MapView &m, MapTieWalk *st, unsigned long long
   st->axis = axis ^ 1;
 }
 
+// The first M points of the cloud (original index < M) by original index: the top of the reference's
+// insertion-built map tree consists of exactly these (a node's ancestors were all inserted before it),
+// so the host can walk that part without the device (map_first_of_two, trg_engine.cpp).
+__global__ __launch_bounds__(256) void k_collect_first(MapView m, int M, float *out_xy) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (size_t)gridDim.x * blockDim.x) {
+    const int pm = m.perm[i];
+    if (pm < M) {
+      out_xy[2 * pm] = m.x[i];
+      out_xy[2 * pm + 1] = m.y[i];
+    }
+  }
+}
+
 // One step with the whole grid scanning (the top of the tree: regions of millions of points); the
 // workgroup that finishes last takes the decision.
 __global__ __launch_bounds__(256) void k_region_walk_grid(MapView m, MapTieWalk *st) {
@@ -2209,6 +2222,9 @@ void launch_sample_nodes(const MapView &m, QueryParams p, const float *cos_t, co
 void launch_map_tied_set(const MapView &m, float qx, float qy, float r0, MapTieSet *d_out,
                          hipStream_t s) {
   hipLaunchKernelGGL(k_map_tied_set, dim3(1), dim3(WAVE), 0, s, m, qx, qy, r0, d_out);
+}
+void launch_collect_first(const MapView &m, int M, float *d_out_xy, hipStream_t s) {
+  hipLaunchKernelGGL(k_collect_first, dim3(blocks_for(m.n, 256, 4096)), dim3(256), 0, s, m, M, d_out_xy);
 }
 void launch_map_tie_walk(const MapView &m, MapTieWalk *d_state, int grid_steps, int block_steps, hipStream_t s) {
   // the top of the tree with the whole grid (cell rows strided over the workgroups), the rest in one
