@@ -1650,7 +1650,10 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
       for (int k = 0; k < ncu_edge && k * stride < 256; ++k) mask[(k * stride) / 32] |= 1u << ((k * stride) % 32);
       HIPCHK(e, hipExtStreamCreateWithCUMask(&e->s_edge, 8, mask));
     } else {
-      HIPCHK(e, hipStreamCreateWithPriority(&e->s_edge, hipStreamNonBlocking, pr_least));
+      // the priority of the main stream (default; lowest leaves a longer tail after the loop: measured
+      // 0.5 ms slower); TRG_EDGE_PRIO=1 (measurements): lowest
+      const bool low = getenv("TRG_EDGE_PRIO") && atoi(getenv("TRG_EDGE_PRIO")) != 0;
+      HIPCHK(e, hipStreamCreateWithPriority(&e->s_edge, hipStreamNonBlocking, low ? pr_least : 0));
     }
     HIPCHK(e, hipStreamCreateWithFlags(&e->s_aux, hipStreamNonBlocking));
   }
