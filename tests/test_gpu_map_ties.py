@@ -20,11 +20,13 @@ def _lattice(n=48, step=0.125, seed=3):
     return xyz[rng.permutation(n * n)]
 
 
-@pytest.mark.parametrize("seed", [3, 4])
-def test_nearest_z_tie_follows_map_tree_order(oa, seed):
+@pytest.mark.parametrize("seed,n", [(3, 48), (4, 48), (5, 144)])
+def test_nearest_z_tie_follows_map_tree_order(oa, seed, n):
+    """(n = 48: the whole insertion tree is inside the host-side top of the tree; n = 144, 20 736
+    points: the walk starts on the host and continues on the device from the region below the top.)"""
     import trg_planner
-    cloud = _lattice(seed=seed)
-    step, n = 0.125, 48
+    cloud = _lattice(n=n, seed=seed)
+    step = 0.125
     rng = np.random.default_rng(seed + 100)
     # edge midpoints (2 points tied), cell centres (4 tied), and lattice-point reflections
     q = []
