@@ -138,7 +138,7 @@ typedef struct TrgStats {
   uint64_t bfs_levels;         /* BFS depth of the last build (device-resident path) */
   uint64_t used_device_bfs;    /* 1: BFS + CSR ran on the GPU; 0: host replay */
   uint64_t bfs_fallbacks;      /* device path declined and the host replay redid the build */
-  uint64_t bfs_max_spin;       /* longest dependency wait (poll iterations) in k_bfs_resolve */
+  uint64_t bfs_max_spin;       /* longest dependency wait (poll iterations) in k_level_resolve */
   uint64_t bfs_host_levels;    /* BFS levels replayed on the host because of an exact distance tie */
   uint64_t map_nn_ties;        /* nearest-map-point queries (trial discs and elevation lookups,
                                   trg.cpp:244-247) that met two MAP points at exactly the same fp32
@@ -260,7 +260,7 @@ TrgStatus trg_engine_voxel_filter(TrgEngine *e, const float *xyz, size_t n, size
  * "debug_gate_margin" = x (widen the band of slope gates left to the host's libm),
  * "debug_spec_bound" = n (cap the speculative next-level sampling launch at n nodes -> top-up
  * launches), "debug_fallback_level" = n (the device BFS declines at level n -> whole-build host
- * replay), "debug_stall_level" = n (k_bfs_resolve leaves one candidate of level n undecided ->
+ * replay), "debug_stall_level" = n (k_level_resolve leaves one candidate of level n undecided ->
  * BFS_ERR_STALL -> the level is taken back and replayed on the host), "debug_lookback_level" = n (one
  * workgroup's commit look-back gives up at level n -> BFS_ERR_LOOKBACK -> whole-build host replay). */
 TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value);

@@ -331,7 +331,7 @@ def test_natural_node_ties_settled_like_the_reference(oa, synth, bits, inplace):
 
 
 def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
-    """k_bfs_resolve's inter-workgroup wait is bounded; when it runs out (BFS_ERR_STALL) the level is
+    """k_level_resolve's inter-workgroup wait is bounded; when it runs out (BFS_ERR_STALL) the level is
     left PARTIALLY decided -- outcomes 0 / 7 in c_outcome, commit and emit have run on them.  The
     hook leaves the middle candidate of one mid-build level undecided (everything that waits for it
     runs into the bound): the engine must take the level back (k_bfs_undo_commit), replay it on the
@@ -400,7 +400,7 @@ def test_statistics_equal_across_repeated_builds(mountain_small):
 
 
 def test_device_build_is_deterministic(oa, mountain_gentle):
-    """k_bfs_resolve lets thousands of lanes decide concurrently; the outcome must not depend on
+    """k_level_resolve lets thousands of lanes decide concurrently; the outcome must not depend on
     timing.  Crowded configuration (S=24), five builds, all equal to the oracle."""
     prm = dict(oa.MOUNTAIN, sample_num=24)
     o = oa.Oracle(**prm)

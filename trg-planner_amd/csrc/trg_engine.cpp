@@ -363,7 +363,7 @@ struct TrgEngine {
   int debug_fallback_level = -1; // test hook: the device BFS declines at this level
   bool tie_inplace = true;       // node-distance ties settled slot by slot on the committed level (off: host level replay)
   int debug_lookback_level = -1; // test hook: one workgroup's commit look-back gives up at this level
-  int debug_stall_level = -1;    // test hook: k_bfs_resolve leaves one candidate of this level undecided
+  int debug_stall_level = -1;    // test hook: k_level_resolve leaves one candidate of this level undecided
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
