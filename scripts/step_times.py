@@ -12,7 +12,7 @@ cloud = synth.mountain_tile(0, 3200, 0, 3125, seed=20250418)
 d = torch.from_numpy(cloud).cuda()
 e = trg_planner.Engine(**dict(MOUNTAIN, sample_num=16))
 e.set_sampler(7, 16)
-for k in range(12):
+for k in range(16):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e.set_global_map_device(d.data_ptr(), cloud.shape[0], 3)

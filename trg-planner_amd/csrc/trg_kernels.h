@@ -292,6 +292,9 @@ void launch_first_insert(const FinDev &F, const BfsDev &B, long long c0, long lo
 void launch_calls_select(const FinDev &F, const BfsDev &B, long long c0, long long c1, int round,
                          int *flag, int *off, int *scan_tmp, int *list, unsigned long long *total,
                          hipStream_t s, int *count_out = nullptr);
+// round 2 over the whole log in one pass (*count must be zero): calls whose pair's first call failed
+void launch_calls_select2_append(const FinDev &F, const BfsDev &B, long long ncalls, int *list, int *count,
+                                 unsigned long long *total, hipStream_t s);
 void launch_fin_insert_count(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
 void launch_fin_scatter(const FinDev &F, const BfsDev &B, long long ncalls, hipStream_t s);
 void launch_fin_rowsort(const FinDev &F, int V, hipStream_t s);
