@@ -140,6 +140,7 @@ def main():
     from trg_planner import synth
 
     from trg_planner import tiled, tiling
+    pinned = None if os.environ.get("TRG_NO_PIN") else tiling.pin_to_gpu_numa(gpu_index, slot=local_rank, nslots=min(world, ndev))
     nx, ny, S, label = WORKLOADS[args.workload]
     # One continuous terrain cut into a cols x rows grid of nx x ny tiles (C4/C5-style: 2x1, 2x2,
     # 4x2 ...); rank == tile.  Every rank holds its core plus a 1.1 m halo and
@@ -259,6 +260,8 @@ def main():
             "config": {
                 "workload": label, "points_per_gpu": n_pts, "V_prime": V, "E_prime": E,
                 "sampler": "counter-based table, seed 7, 16 bits",
+                "host_thread": ("pinned to CPUs %d-%d of NUMA node %d (the GPU's)" % (pinned[1], pinned[2], pinned[0]))
+                if pinned else "not pinned",
                 "sharding": (f"{cols}x{rows} tiles of one continuous terrain, one per rank, core + "
                              f"1.1 m halo; boundary edges stitched on the GPUs, 2 all-gather-v over "
                              f"{ {'nccl': 'RCCL (device tensors)', 'gloo': 'gloo (host tensors: rehearsal)'}.get(stitch_info['backend'], stitch_info['backend'])} "
