@@ -86,11 +86,6 @@ void launch_cell_count(const float *d_xyz, size_t n, size_t stride, float x0, fl
 hipError_t voxel_grid_filter(const float *d_xyz, size_t n, size_t stride, float leaf, float *d_out,
                              size_t *n_out, int *status, hipStream_t s);
 void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, hipStream_t s);
-void launch_scatter(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
-                    const int *d_rank, const int *d_cell_start, float *x, float *y, float *z,
-                    int *perm, hipStream_t s);
-void launch_cell_sort(int ncell, const int *d_cell_start, float *x, float *y, float *z, int *perm,
-                      hipStream_t s);
 // scatter + per-cell sort through a scratch array of n 16-byte records (one store per point)
 void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
                              const int *d_rank, int ncell, const int *d_cell_start, void *d_aos, float *x,

@@ -1358,24 +1358,10 @@ __global__ __launch_bounds__(256) void k_scan_add(int *out, int m, const int *ti
   if (blockIdx.x == 0 && threadIdx.x == 0) out[m] = tile_sum[nt];
 }
 
-__global__ __launch_bounds__(256) void k_scatter(const float *xyz, size_t n, size_t stride,
-                                                 const int *cell_of, const int *rank,
-                                                 const int *cell_start, float *x, float *y, float *z,
-                                                 int *perm) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int dst = cell_start[cell_of[i]] + rank[i];
-    x[dst] = xyz[i * stride];
-    y[dst] = xyz[i * stride + 1];
-    z[dst] = xyz[i * stride + 2];
-    perm[dst] = (int)i;
-  }
-}
-
-// The same scatter with ONE 16-byte store per point (x, y, z, original index) into a scratch array:
-// the destinations are random (the cloud arrives shuffled), and a random 4-byte store costs a memory
-// transaction just like a 16-byte one -- four of them per point made k_scatter the longest kernel
-// of the index build.  k_cell_sort_aos turns the records into the SoA arrays the queries read.
+// Points go to their place in the cell order with ONE 16-byte store each (x, y, z, original index) into
+// a scratch array: the destinations are random (the cloud arrives shuffled), and a random 4-byte store
+// costs a memory transaction just like a 16-byte one -- four SoA stores per point were 1.0 ms at C3,
+// the longest kernel of the index build; this is 0.3 ms.  k_cell_sort_aos turns the records into the SoA arrays the queries read.
 __global__ __launch_bounds__(256) void k_scatter_aos(const float *xyz, size_t n, size_t stride,
                                                      const int *cell_of, const int *rank,
                                                      const int *cell_start, float4 *aos) {
@@ -1413,36 +1399,7 @@ __device__ __forceinline__ void cell_insertion_sort(float *x, float *y, float *z
 // A workgroup owns 256 consecutive cells, i.e. one contiguous range of the sorted arrays: it is
 // staged in LDS with coalesced loads, every thread sorts its own cell there, and the range is
 // written back coalesced (ranges too long for LDS are sorted in place in global memory).
-__global__ __launch_bounds__(256) void k_cell_sort(int ncell, const int *cell_start, float *x,
-                                                   float *y, float *z, int *perm) {
-  __shared__ float lx[CSORT_CAP], ly[CSORT_CAP], lz[CSORT_CAP];
-  __shared__ int lp[CSORT_CAP];
-  const int c0 = blockIdx.x * blockDim.x;
-  const int c = c0 + threadIdx.x;
-  const int p0 = cell_start[c0], p1 = cell_start[min(c0 + (int)blockDim.x, ncell)];
-  const int n = p1 - p0;
-  if (n > CSORT_CAP) {
-    if (c < ncell) cell_insertion_sort(x, y, z, perm, cell_start[c], cell_start[c + 1]);
-    return;
-  }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    lx[i] = x[p0 + i];
-    ly[i] = y[p0 + i];
-    lz[i] = z[p0 + i];
-    lp[i] = perm[p0 + i];
-  }
-  __syncthreads();
-  if (c < ncell) cell_insertion_sort(lx, ly, lz, lp, cell_start[c] - p0, cell_start[c + 1] - p0);
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    x[p0 + i] = lx[i];
-    y[p0 + i] = ly[i];
-    z[p0 + i] = lz[i];
-    perm[p0 + i] = lp[i];
-  }
-}
-
-// k_cell_sort reading the 16-byte records k_scatter_aos left and writing the SoA arrays
+// (the records k_scatter_aos left are read, the SoA arrays the queries use are written)
 __global__ __launch_bounds__(256) void k_cell_sort_aos(int ncell, const int *cell_start, const float4 *aos,
                                                        float *x, float *y, float *z, int *perm) {
   __shared__ float lx[CSORT_CAP], ly[CSORT_CAP], lz[CSORT_CAP];
@@ -2166,12 +2123,6 @@ void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, h
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(256), 0, s, d_tmp, nt);
   hipLaunchKernelGGL(k_scan_add, dim3(nt), dim3(256), 0, s, d_out, m, d_tmp, nt);
 }
-void launch_scatter(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
-                    const int *d_rank, const int *d_cell_start, float *x, float *y, float *z,
-                    int *perm, hipStream_t s) {
-  hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, d_xyz, n, stride,
-                     d_cell_of, d_rank, d_cell_start, x, y, z, perm);
-}
 void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
                              const int *d_rank, int ncell, const int *d_cell_start, void *d_aos, float *x,
                              float *y, float *z, int *perm, hipStream_t s) {
@@ -2179,11 +2130,6 @@ void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const 
                      d_cell_of, d_rank, d_cell_start, (float4 *)d_aos);
   hipLaunchKernelGGL(k_cell_sort_aos, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d_cell_start,
                      (const float4 *)d_aos, x, y, z, perm);
-}
-void launch_cell_sort(int ncell, const int *d_cell_start, float *x, float *y, float *z, int *perm,
-                      hipStream_t s) {
-  hipLaunchKernelGGL(k_cell_sort, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d_cell_start,
-                     x, y, z, perm);
 }
 
 void launch_probe_collision(const MapView &m, QueryParams p, float threshold, const float *d_xy,
