@@ -73,6 +73,51 @@ int main() {
       }
     }
   }
+  // updateGraph cycles (trg.cpp:456-489): after the copy assignment the graph grows by appended
+  // keys (nodes[node_id] = node for the next dense ids), then cleanGraph renumbers again -- several
+  // cycles on the same container, appended counts crossing rehash thresholds
+  {
+    std::unordered_map<int, int> nodes2;
+    trg::MapOrderSim sim2;
+    for (int i = 0; i < 64736; ++i) {
+      nodes2[i] = i;
+      sim2.insert_next();
+    }
+    const int grow[] = {0, 1, 7, 300, 2500, 40000, 3, 90000, 12};
+    for (int cyc = 0; cyc < 9; ++cyc) {
+      // cleanGraph
+      std::unordered_map<int, int> new_nodes;
+      trg::MapOrderSim new_sim;
+      int new_id = 0;
+      for (auto &kv : nodes2) {
+        rng = rng * 1664525u + 1013904223u;
+        if ((rng >> 27) == 0 && kv.first != 0) continue;  // drop ~3%
+        new_nodes[new_id] = kv.first;
+        new_sim.insert_next();
+        new_id++;
+      }
+      nodes2 = new_nodes;
+      sim2.assign_from(new_sim);
+      if (!same_order(nodes2, sim2)) {
+        printf("update cycle %d: assign mismatch\n", cyc);
+        return 1;
+      }
+      // the update appends nodes
+      for (int k = 0; k < grow[cyc]; ++k) {
+        const int id = (int)nodes2.size();
+        nodes2[id] = id;
+        sim2.insert_next();
+        if ((k < 32 || k % 4099 == 0) && !same_order(nodes2, sim2)) {
+          printf("update cycle %d: append mismatch at %d\n", cyc, k);
+          return 1;
+        }
+      }
+      if (!same_order(nodes2, sim2)) {
+        printf("update cycle %d: append mismatch\n", cyc);
+        return 1;
+      }
+    }
+  }
   printf("ok\n");
   return 0;
 }

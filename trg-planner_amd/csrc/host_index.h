@@ -263,6 +263,28 @@ class NodeGrid {
     dd += (py_[s] - qy) * (py_[s] - qy);
     return dd;
   }
+  // Is any slot within r of (qx, qy), as kd_nearest_range2 would report (d2 <= r * r, kdtree.c:270-301)?
+  // 1 yes, 0 no, -1 cannot say without the tree: a slot within rounding of the radius may or may not be
+  // reached by the tree walk (it prunes the far side of a split with |dx| >= r), so the caller asks the
+  // tree replica in that (practically never occurring) case.
+  int within(float qx, float qy, float r) const {
+    const float r2 = r * r;
+    const float lo = r2 * (1.0f - 4e-6f), hi = r2 * (1.0f + 4e-6f);
+    const float rad = r * 1.001f + 1e-6f;
+    const int cx0 = clampi((int)std::floor((qx - rad - x0_) * inv_), 0, W_ - 1);
+    const int cx1 = clampi((int)std::floor((qx + rad - x0_) * inv_), 0, W_ - 1);
+    const int cy0 = clampi((int)std::floor((qy - rad - y0_) * inv_), 0, H_ - 1);
+    const int cy1 = clampi((int)std::floor((qy + rad - y0_) * inv_), 0, H_ - 1);
+    bool doubt = false;
+    for (int yy = cy0; yy <= cy1; ++yy)
+      for (int xx = cx0; xx <= cx1; ++xx)
+        for (int s = head_[(size_t)yy * W_ + xx]; s >= 0; s = next_[s]) {
+          const float dd = dist2(s, qx, qy);
+          if (dd < lo) return 1;
+          if (dd <= hi) doubt = true;
+        }
+    return doubt ? -1 : 0;
+  }
 
   void insert(float x, float y) {  // slot index == insertion order
     const int slot = (int)px_.size();

@@ -1047,7 +1047,13 @@ int add_node_host(TrgEngine *e, float x, float y, float z, int state) {
   e->nz.push_back(z);
   e->nstate.push_back(state);
   e->ncid.push_back((int)e->ncid.size());
-  e->order_map[id] = id;  // graph.nodes[node_id] = node (trg.cpp:248)
+  // graph.nodes[node_id] = node (trg.cpp:248): into whichever representation of the container is current
+  // (after a device build or a cleanGraph the keys are dense and ascending: the O(1) replica serves)
+  if (e->real_map_stale) {
+    e->nodes_sim.insert_next();
+  } else {
+    e->order_map[id] = id;
+  }
   e->kd_insert_order.push_back(id);
   e->grid.insert(x, y);
   e->edges.grow_nodes(e->nx.size());
@@ -1488,11 +1494,10 @@ void clean_graph(TrgEngine *e) {
   std::vector<char> is_del(V, 0);
   int new_id = 0;
   // new ids follow the iteration order of the reference's unordered_map (trg.cpp:497-504)
-  std::unordered_map<int, int> new_nodes;
-  for (auto &kv : e->order_map) {
-    const int id = kv.first;
+  std::vector<int> order;
+  node_map_order(e, order);
+  for (const int id : order) {
     if (e->nstate[id] == TRG_NODE_INVALID || e->edges.deg[id] < 1) continue;
-    new_nodes[new_id] = new_id;
     old2new[id] = new_id;
     keep_order.push_back(id);
     new_id++;
@@ -1526,10 +1531,21 @@ void clean_graph(TrgEngine *e) {
   e->ncid.swap(cid2);
   e->edges = std::move(ep);
   e->node_id = Vn;
-  // global_graph.nodes = new_nodes; then the node tree is refilled in that map's iteration order
-  e->order_map = new_nodes;
-  e->kd_insert_order.clear();
-  for (auto &kv : e->order_map) e->kd_insert_order.push_back(kv.first);
+  // new_nodes[new_id] = node for the dense new ids (trg.cpp:502), global_graph.nodes = new_nodes (:526:
+  // bucket count, policy and element order of the source are taken over -- what moving it in leaves
+  // behind); then the node tree is refilled in that map's iteration order
+  if (e->real_map_stale) {
+    MapOrderSim new_nodes;
+    new_nodes.fill((size_t)Vn);
+    e->nodes_sim.assign_from(new_nodes);
+    e->nodes_sim.iteration_order(e->kd_insert_order);
+  } else {
+    std::unordered_map<int, int> new_nodes;
+    for (int k = 0; k < Vn; ++k) new_nodes[k] = k;
+    e->order_map = std::move(new_nodes);
+    e->kd_insert_order.clear();
+    for (auto &kv : e->order_map) e->kd_insert_order.push_back(kv.first);
+  }
   e->kd_order_dirty = false;
   e->kd_valid = false;
   grid_rebuild(e);
@@ -1564,21 +1580,30 @@ TrgStatus set_local_graph(TrgEngine *e) {
     e->local_map.clear();
     return TRG_OK;
   }
-  // membership: any local-map point within robot_size/2 of the node (a disc-emptiness probe)
-  std::vector<float> xy(2 * V);
-  for (size_t i = 0; i < V; ++i) {
-    xy[2 * i] = e->nx[i];
-    xy[2 * i + 1] = e->ny[i];
-  }
+  // membership: any local-map point within robot_size/2 of the node (a disc-emptiness probe); only
+  // nodes inside the local map's bounding box (grown by that radius) can have one
   std::vector<int32_t> n(V, 0);
   if (e->lmap.valid) {
-    QueryParams q = qparams(e);
-    TrgParams save = e->prm;
-    e->prm.robot_size = (float)(save.robot_size * 0.5);
-    TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), V, nullptr, nullptr, n.data());
-    e->prm = save;
-    (void)q;
-    if (st != TRG_OK) return st;
+    const float rr = (float)(e->prm.robot_size * 0.5) * 1.01f + 1e-4f;
+    const float bx0 = e->lmap.bounds[0] - rr, by0 = e->lmap.bounds[1] - rr;
+    const float bx1 = e->lmap.bounds[2] + rr, by1 = e->lmap.bounds[3] + rr;
+    std::vector<int> cand;
+    std::vector<float> xy;
+    for (size_t i = 0; i < V; ++i)
+      if (e->nx[i] >= bx0 && e->nx[i] <= bx1 && e->ny[i] >= by0 && e->ny[i] <= by1) {
+        cand.push_back((int)i);
+        xy.push_back(e->nx[i]);
+        xy.push_back(e->ny[i]);
+      }
+    if (!cand.empty()) {
+      std::vector<int32_t> nc(cand.size(), 0);
+      TrgParams save = e->prm;
+      e->prm.robot_size = (float)(save.robot_size * 0.5);
+      TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), cand.size(), nullptr, nullptr, nc.data());
+      e->prm = save;
+      if (st != TRG_OK) return st;
+      for (size_t k = 0; k < cand.size(); ++k) n[cand[k]] = nc[k];
+    }
   }
   e->local_map.clear();  // resetGraph("local"): clear() keeps the bucket array, as the reference's does
   std::vector<int> global_order;
@@ -1974,12 +1999,17 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   if (st != TRG_OK) return st;
   e->epoch++;
   e->dev_csr_valid = false;
-  ensure_real_map(e);
+  const bool trace_up = getenv("TRG_TIMING") != nullptr;
+  auto t_up = Clock::now();
+  auto lap_up = [&](const char *what) {
+    if (trace_up) fprintf(stderr, "[trg update] %-28s %8.3f ms\n", what, ms_since(t_up));
+  };
   ensure_pool(e);
   ensure_host_grid(e);
   materialize_kd_order(e);  // nodes created below are appended to the existing insertion order
   e->calls.clear();
   e->pending_calls.clear();
+  lap_up("host structures ready");
 
   // per local node: invalidate / keep frontier / revalidate (trg.cpp:464-481)
   const size_t L = e->local_nodes.size();
@@ -2021,6 +2051,7 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   // themselves are replayed one root after the other, as the reference runs them.  wireEdge's
   // dedupe does not influence any node decision, so the logged calls are evaluated and applied once
   // at the end, in program order (first successful call per pair wins).
+  lap_up("local nodes classified");
   st = ensure_chunks(e);
   if (st != TRG_OK) return st;
   for (size_t g0 = 0; g0 < expand_queue.size(); g0 += TrgEngine::CHUNK_MAX) {
@@ -2034,14 +2065,21 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
       if (st != TRG_OK) return st;
     }
   }
+  lap_up("roots expanded");
   st = flush_pending(e, true);
   if (st != TRG_OK) return st;
+  lap_up("deferred edges evaluated");
   apply_calls(e, 0);
+  lap_up("calls applied");
   if (e->keep_preclean) snapshot_csr(e, e->csr_pre);
   clean_graph(e);
+  lap_up("cleanGraph");
   snapshot_csr(e, e->csr_global);
+  lap_up("CSR snapshot");
   read_counters(e);
-  return set_local_graph(e);  // cleanGraph(true) -> setLocalGraph (trg.cpp:532-534)
+  st = set_local_graph(e);
+  lap_up("setLocalGraph");
+  return st;  // cleanGraph(true) -> setLocalGraph (trg.cpp:532-534)
 }
 
 TrgStatus trg_engine_export_csr(TrgEngine *e, TrgKind kind, TrgCsrView *out) {
@@ -2410,7 +2448,10 @@ TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, 
   if (m && (!xy || !flag)) return e->fail(TRG_ERR_INVALID_ARG, "null arguments");
   // trg.cpp:780-803: check = pos + 2*robot_size*normalize(pos - local root); frontier iff no global
   // node within robot_size of check AND no local-map point within robot_size/2 of it
-  kd_sync(e);
+  // "no global node within robot_size" only asks whether the range query is empty: the node grid answers
+  // that without the tree replica (building it costs O(V log V) per update); the replica is consulted
+  // only for a node within rounding of the radius, where the tree's pruning decides
+  ensure_host_grid(e);
   std::vector<float> chk(2 * m);
   std::vector<int> hits;
   std::vector<char> blocked(m, 0);
@@ -2425,8 +2466,13 @@ TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, 
     const float k = 2 * e->prm.robot_size;
     chk[2 * i] = xy[2 * i] + k * dx;
     chk[2 * i + 1] = xy[2 * i + 1] + k * dy;
-    e->kd.range(chk[2 * i], chk[2 * i + 1], e->prm.robot_size, hits);
-    blocked[i] = !hits.empty();
+    int w = e->grid.ready() ? e->grid.within(chk[2 * i], chk[2 * i + 1], e->prm.robot_size) : -1;
+    if (w < 0) {
+      kd_sync(e);
+      e->kd.range(chk[2 * i], chk[2 * i + 1], e->prm.robot_size, hits);
+      w = hits.empty() ? 0 : 1;
+    }
+    blocked[i] = w != 0;
   }
   std::vector<int32_t> n(m, 0);
   if (e->lmap.valid && m) {
