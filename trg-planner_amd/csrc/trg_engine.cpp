@@ -1491,7 +1491,6 @@ void clean_graph(TrgEngine *e) {
   const size_t V = e->nx.size();
   std::vector<int> old2new(V, 0);  // old2new[] default-constructs 0 in the reference too
   std::vector<int> keep_order;     // old ids in the order they receive new ids
-  std::vector<char> is_del(V, 0);
   int new_id = 0;
   // new ids follow the iteration order of the reference's unordered_map (trg.cpp:497-504)
   std::vector<int> order;
@@ -1501,11 +1500,10 @@ void clean_graph(TrgEngine *e) {
     old2new[id] = new_id;
     keep_order.push_back(id);
     new_id++;
-    for (int ed = e->edges.head[id]; ed >= 0; ed = e->edges.next[ed]) {
-      const int d = e->edges.dst[ed];
-      if (e->nstate[d] == TRG_NODE_INVALID) is_del[d] = 1;
-    }
   }
+  // trg.cpp:505-520 drops the edges of kept nodes that lead to a node it deletes.  A kept node has edges,
+  // so the only deleted nodes an edge can lead to are Invalid ones: "is deleted" is the state test below
+  // (no separate marking pass over the 700 k-entry edge pool).
   const int Vn = new_id;
   std::vector<float> x2(Vn), y2(Vn), z2(Vn);
   std::vector<int> st2(Vn), cid2(Vn);
@@ -1520,7 +1518,7 @@ void clean_graph(TrgEngine *e) {
     cid2[k] = e->ncid[old];
     for (int ed = e->edges.head[old]; ed >= 0; ed = e->edges.next[ed]) {
       const int d = e->edges.dst[ed];
-      if (is_del[d]) continue;
+      if (e->nstate[d] == TRG_NODE_INVALID) continue;
       ep.push(k, old2new[d], e->edges.w[ed], e->edges.dist[ed]);
     }
   }
