@@ -309,6 +309,7 @@ struct TrgEngine {
   // iteration order (map_order_sim.h); the real map is rebuilt from it only if a host path needs it.
   MapOrderSim nodes_sim;
   bool real_map_stale = false;
+  std::vector<int> last_new2old;  // of the last host cleanGraph: old id of every surviving node
   EdgePool edges;
   int node_id = 0;
   float root_pos[2] = {0, 0};
@@ -654,8 +655,11 @@ TrgStatus ensure_sync_scratch(TrgEngine *e, size_t m) {
 
 DevMap *pick_map(TrgEngine *e, TrgKind k) { return k == TRG_KIND_LOCAL ? &e->lmap : &e->gmap; }
 
+// strm: the stream the probe runs in (the main stream may still hold look-ahead work of a finished replay that
+// nobody needs to wait for: the maps are read-only here)
 TrgStatus collision_sync(TrgEngine *e, DevMap &m, float threshold, const float *xy, size_t cnt,
-                         int32_t *flag, int32_t *c_out, int32_t *n_out) {
+                         int32_t *flag, int32_t *c_out, int32_t *n_out, hipStream_t strm = nullptr) {
+  if (!strm) strm = e->s_main;
   if (!m.valid) {
     // empty map: kd_nearest_range on an empty tree returns no hits -> collision (trg.cpp:749-752)
     for (size_t i = 0; i < cnt; ++i) {
@@ -672,16 +676,16 @@ TrgStatus collision_sync(TrgEngine *e, DevMap &m, float threshold, const float *
     if (st != TRG_OK) return st;
     memcpy(e->sy_in.h, xy + 2 * off, m_ * 2 * sizeof(float));
     HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 2 * sizeof(float), hipMemcpyHostToDevice,
-                             e->s_main));
+                             strm));
     launch_probe_collision(m.view, qparams(e), threshold, e->sy_in.d, (int)m_, e->sy_i0.d,
-                           e->sy_i1.d, e->sy_i2.d, e->d_ctr, e->s_main);
+                           e->sy_i1.d, e->sy_i2.d, e->d_ctr, strm);
     HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             e->s_main));
+                             strm));
     HIPCHK(e, hipMemcpyAsync(e->sy_i1.h, e->sy_i1.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             e->s_main));
+                             strm));
     HIPCHK(e, hipMemcpyAsync(e->sy_i2.h, e->sy_i2.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             e->s_main));
-    HIPCHK(e, hipStreamSynchronize(e->s_main));
+                             strm));
+    HIPCHK(e, hipStreamSynchronize(strm));
     HIPCHK(e, hipGetLastError());
     if (flag) memcpy(flag + off, e->sy_i0.h, m_ * sizeof(int));
     if (c_out) memcpy(c_out + off, e->sy_i1.h, m_ * sizeof(int));
@@ -1522,6 +1526,7 @@ void clean_graph(TrgEngine *e) {
       ep.push(k, old2new[d], e->edges.w[ed], e->edges.dist[ed]);
     }
   }
+  e->last_new2old = keep_order;
   e->nx.swap(x2);
   e->ny.swap(y2);
   e->nz.swap(z2);
@@ -1570,7 +1575,38 @@ void read_counters(TrgEngine *e) {
 }
 
 // ---- local graph (trg.cpp:211-231) ---------------------------------------------------------------
-TrgStatus set_local_graph(TrgEngine *e) {
+// membership of the local graph (trg.cpp:211-231): n[i] != 0 iff a local-map point lies within
+// robot_size / 2 of node i (a disc-emptiness probe); only nodes inside the local map's bounding box
+// (grown by that radius) can have one
+TrgStatus local_membership(TrgEngine *e, std::vector<int32_t> &n) {
+  const size_t V = e->nx.size();
+  n.assign(V, 0);
+  if (!e->lmap.valid || V == 0) return TRG_OK;
+  const float rr = (float)(e->prm.robot_size * 0.5) * 1.01f + 1e-4f;
+  const float bx0 = e->lmap.bounds[0] - rr, by0 = e->lmap.bounds[1] - rr;
+  const float bx1 = e->lmap.bounds[2] + rr, by1 = e->lmap.bounds[3] + rr;
+  std::vector<int> cand;
+  std::vector<float> xy;
+  for (size_t i = 0; i < V; ++i)
+    if (e->nx[i] >= bx0 && e->nx[i] <= bx1 && e->ny[i] >= by0 && e->ny[i] <= by1) {
+      cand.push_back((int)i);
+      xy.push_back(e->nx[i]);
+      xy.push_back(e->ny[i]);
+    }
+  if (cand.empty()) return TRG_OK;
+  std::vector<int32_t> nc(cand.size(), 0);
+  TrgParams save = e->prm;
+  e->prm.robot_size = (float)(save.robot_size * 0.5);
+  TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), cand.size(), nullptr, nullptr, nc.data(), e->s_aux);
+  e->prm = save;
+  if (st != TRG_OK) return st;
+  for (size_t k = 0; k < cand.size(); ++k) n[cand[k]] = nc[k];
+  return TRG_OK;
+}
+
+// member: the membership flags if the caller already has them (updateGraph probes before its host-side
+// cleanGraph, while the GPU is still awake: after ~10 ms without work the first launch takes ~2 ms)
+TrgStatus set_local_graph(TrgEngine *e, const std::vector<int32_t> *member = nullptr) {
   e->local_nodes.clear();
   e->lkd.clear();
   const size_t V = e->nx.size();
@@ -1578,31 +1614,13 @@ TrgStatus set_local_graph(TrgEngine *e) {
     e->local_map.clear();
     return TRG_OK;
   }
-  // membership: any local-map point within robot_size/2 of the node (a disc-emptiness probe); only
-  // nodes inside the local map's bounding box (grown by that radius) can have one
-  std::vector<int32_t> n(V, 0);
-  if (e->lmap.valid) {
-    const float rr = (float)(e->prm.robot_size * 0.5) * 1.01f + 1e-4f;
-    const float bx0 = e->lmap.bounds[0] - rr, by0 = e->lmap.bounds[1] - rr;
-    const float bx1 = e->lmap.bounds[2] + rr, by1 = e->lmap.bounds[3] + rr;
-    std::vector<int> cand;
-    std::vector<float> xy;
-    for (size_t i = 0; i < V; ++i)
-      if (e->nx[i] >= bx0 && e->nx[i] <= bx1 && e->ny[i] >= by0 && e->ny[i] <= by1) {
-        cand.push_back((int)i);
-        xy.push_back(e->nx[i]);
-        xy.push_back(e->ny[i]);
-      }
-    if (!cand.empty()) {
-      std::vector<int32_t> nc(cand.size(), 0);
-      TrgParams save = e->prm;
-      e->prm.robot_size = (float)(save.robot_size * 0.5);
-      TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), cand.size(), nullptr, nullptr, nc.data());
-      e->prm = save;
-      if (st != TRG_OK) return st;
-      for (size_t k = 0; k < cand.size(); ++k) n[cand[k]] = nc[k];
-    }
+  std::vector<int32_t> own;
+  if (!member || member->size() != V) {
+    TrgStatus st = local_membership(e, own);
+    if (st != TRG_OK) return st;
+    member = &own;
   }
+  const std::vector<int32_t> &n = *member;
   e->local_map.clear();  // resetGraph("local"): clear() keeps the bucket array, as the reference's does
   std::vector<int> global_order;
   node_map_order(e, global_order);
@@ -2067,6 +2085,9 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   st = flush_pending(e, true);
   if (st != TRG_OK) return st;
   lap_up("deferred edges evaluated");
+  std::vector<int32_t> member_old;  // local-graph membership of the nodes as they are now (positions do not change)
+  st = local_membership(e, member_old);
+  if (st != TRG_OK) return st;
   apply_calls(e, 0);
   lap_up("calls applied");
   if (e->keep_preclean) snapshot_csr(e, e->csr_pre);
@@ -2075,7 +2096,10 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   snapshot_csr(e, e->csr_global);
   lap_up("CSR snapshot");
   read_counters(e);
-  st = set_local_graph(e);
+  std::vector<int32_t> member_new(e->nx.size(), 0);
+  for (size_t k = 0; k < member_new.size() && k < e->last_new2old.size(); ++k)
+    member_new[k] = member_old[e->last_new2old[k]];
+  st = set_local_graph(e, &member_new);
   lap_up("setLocalGraph");
   return st;  // cleanGraph(true) -> setLocalGraph (trg.cpp:532-534)
 }
