@@ -290,7 +290,8 @@ def main():
                 "edge_evals_gpu": st["edge_evals_gpu"], "nn_ties": st["nn_ties"], "map_nn_ties": st["map_nn_ties"],
                 "gate_uncertain": st["gate_uncertain"], "bfs_levels": st["bfs_levels"],
                 "used_device_bfs": st["used_device_bfs"], "bfs_fallbacks": st["bfs_fallbacks"],
-                "bfs_host_levels": st["bfs_host_levels"],
+                "bfs_host_levels": st["bfs_host_levels"], "bfs_ticket_reruns": st["bfs_ticket_reruns"],
+                "presampled_nodes": st["presampled_nodes"],
                 "bfs_max_spin": st["bfs_max_spin"], "ms_bfs_loop": st["ms_bfs_loop"],
                 "ms_deferred": st["ms_deferred"], "ms_rare_events": st["ms_rare_events"],
                 "ms_set_map_total": st["ms_set_map_total"],

@@ -158,6 +158,10 @@ typedef struct TrgStats {
                                   bytes_spec_kernel is speculation on candidates that merged */
   double ms_rare_events;       /* device path: wall time inside the level loop spent repairing rare events
                                   (map-point ties, uncertain slope gates, node ties, host level replays) */
+  uint64_t bfs_ticket_reruns;  /* device path: resolve launches repeated with start tickets as workgroup indices
+                                  after a bounded inter-workgroup wait ran out */
+  uint64_t presampled_nodes;   /* device path: expanded nodes whose samples were already there when their level's
+                                  sampling kernel started (drawn inside the previous level's resolve launch) */
 } TrgStats;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -330,28 +330,34 @@ def test_natural_node_ties_settled_like_the_reference(oa, synth, bits, inplace):
     assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
 
 
-def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
+@pytest.mark.parametrize("rerun_fails", [False, True], ids=["ticketed-repeat", "host-replay"])
+def test_stalled_resolve_is_undone_and_repeated(oa, mountain_small, rerun_fails):
     """k_level_resolve's inter-workgroup wait is bounded; when it runs out (BFS_ERR_STALL) the level is
     left PARTIALLY decided -- outcomes 0 / 7 in c_outcome, commit and emit have run on them.  The
     hook leaves the middle candidate of one mid-build level undecided (everything that waits for it
-    runs into the bound): the engine must take the level back (k_bfs_undo_commit), replay it on the
-    host and continue on the device, and the graph must still equal the oracle's."""
+    runs into the bound): the engine must take the level back (k_bfs_undo_slots) and repeat the launch
+    with start tickets as workgroup indices (waits are then for running workgroups by construction);
+    if that repeat stalls as well (debug_wait_rerun) the level is replayed on the host.  Either way the
+    device goes on and the graph must still equal the oracle's."""
     prm = dict(oa.MOUNTAIN, sample_num=10)
     e0 = _engine(prm)
     e0.set_sampler(21, 16)
     e0.set_global_map(mountain_small)
     e0.init_graph([15.0, 15.0, 0.0])
     natural = e0.stats()["bfs_host_levels"]  # this cloud has one real nearest-node tie (level 71)
+    assert e0.stats()["bfs_ticket_reruns"] == 0
     e0.close()
     e = _engine(prm)
     e.set_sampler(21, 16)
     e.set_option("keep_preclean", 1)
     e.set_option("debug_stall_level", 9)
+    e.set_option("debug_wait_rerun", 1 if rerun_fails else 0)
     e.set_global_map(mountain_small)
     e.init_graph([15.0, 15.0, 0.0])
     st = e.stats()
     assert st["used_device_bfs"] == 1 and st["bfs_fallbacks"] == 0, (st, e.fallback_reason)
-    assert st["bfs_host_levels"] == natural + 1, (st["bfs_host_levels"], natural)
+    assert st["bfs_ticket_reruns"] == 1, st["bfs_ticket_reruns"]
+    assert st["bfs_host_levels"] == natural + (1 if rerun_fails else 0), (st["bfs_host_levels"], natural)
     o = oa.Oracle(**prm)
     o.set_sampler(21, 0, 16)
     o.set_global_map(mountain_small)
@@ -363,23 +369,60 @@ def test_stalled_resolve_is_undone_and_replayed_on_host(oa, mountain_small):
     assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
 
 
-def test_failed_commit_lookback_falls_back_to_the_host_replay(oa, mountain_small):
+@pytest.mark.parametrize("rerun_fails", [False, True], ids=["ticketed-repeat", "host-fallback"])
+def test_failed_commit_lookback_is_repeated(oa, mountain_small, rerun_fails):
     """The commit's look-back scan waits for lower workgroups with a bound; when it runs out (another
-    process's kernels on the card) the level's numbering is void and the whole build is redone by the
-    host replay.  The hook makes one workgroup of level 7 give up."""
+    process's kernels on the card) the level's numbering is void: the grid reservations are taken back
+    from the slots' outcomes and the launch is repeated with start tickets.  Only if the repeat fails as
+    well (debug_wait_rerun) the whole build is redone by the host replay.  The hook makes one workgroup
+    of level 7 give up."""
     prm = dict(oa.MOUNTAIN, sample_num=10)
     e = _engine(prm)
     e.set_sampler(21, 16)
     e.set_option("debug_lookback_level", 7)
+    e.set_option("debug_wait_rerun", 1 if rerun_fails else 0)
     e.set_global_map(mountain_small)
     e.init_graph([15.0, 15.0, 0.0])
     st = e.stats()
-    assert st["bfs_fallbacks"] == 1 and "look-back" in e.fallback_reason, (st, e.fallback_reason)
+    if rerun_fails:
+        assert st["bfs_fallbacks"] == 1 and "look-back" in e.fallback_reason, (st, e.fallback_reason)
+    else:
+        assert st["bfs_fallbacks"] == 0 and st["used_device_bfs"] == 1, (st, e.fallback_reason)
+        assert st["bfs_ticket_reruns"] == 1
     o = oa.Oracle(**prm)
     o.set_sampler(21, 0, 16)
     o.set_global_map(mountain_small)
     assert o.init_graph([15.0, 15.0, 0.0])
     assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
+
+
+@pytest.mark.parametrize("mode", ["presample_off", "tickets_always"])
+def test_resolve_launch_variants_build_the_same_graph(oa, mountain_small, mode):
+    """The p_role workgroups (pure sampling of the next level inside the resolve launch) and the ticketed
+    workgroup order are optimisations / safety nets: with the first switched off, or the second always
+    on, the graph is the same, and the default build really takes most of its samples from p_role."""
+    prm = dict(MOUNTAIN_S16)
+    e = _engine(prm)
+    e.set_sampler(7, 16)
+    e.set_global_map(mountain_small)
+    e.init_graph([15.0, 15.0, 0.0])
+    g0 = e.graph("global")
+    st0 = e.stats()
+    assert st0["used_device_bfs"] == 1
+    assert st0["presampled_nodes"] > 0.8 * st0["expanded_nodes"], (st0["presampled_nodes"], st0["expanded_nodes"])
+    e.close()
+    e = _engine(prm)
+    e.set_sampler(7, 16)
+    e.set_option("presample" if mode == "presample_off" else "resolve_tickets", 0 if mode == "presample_off" else 1)
+    e.set_global_map(mountain_small)
+    e.init_graph([15.0, 15.0, 0.0])
+    g1 = e.graph("global")
+    st1 = e.stats()
+    assert st1["used_device_bfs"] == 1 and st1["bfs_fallbacks"] == 0
+    assert st1["presampled_nodes"] == 0  # (ticketed launches carry no p_role workgroups)
+    assert_graph_equal(g1, g0, 0.0)
+    for k in ("trials", "samples", "created_nodes", "invalid_nodes", "bytes_sample_kernel"):
+        assert st0[k] == st1[k], (k, st0[k], st1[k])
 
 
 def test_statistics_equal_across_repeated_builds(mountain_small):

@@ -365,6 +365,10 @@ struct TrgEngine {
   bool tie_inplace = true;       // node-distance ties settled slot by slot on the committed level (off: host level replay)
   int debug_lookback_level = -1; // test hook: one workgroup's commit look-back gives up at this level
   int debug_stall_level = -1;    // test hook: k_level_resolve leaves one candidate of this level undecided
+  bool debug_wait_rerun = false; // test hook: the ticketed repeat of that launch runs into the same hook
+  bool presample = true;         // pure part of the next level's expansion inside the resolve launch (p_role workgroups)
+  int resolve_tickets = 0;       // 1: every resolve launch takes its workgroup indices from start tickets (default: only
+                                 // the repeat of a launch whose bounded wait ran out)
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm
   BfsBuffers *bfs = nullptr;
   std::string bfs_fallback_reason;
@@ -1707,6 +1711,8 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
   e->bfs = new BfsBuffers();
   e->stitch = new StitchBufs();
   if (const char *env = getenv("TRG_REPLAY")) e->use_device_bfs = std::string(env) != "host";
+  if (const char *env = getenv("TRG_PRESAMPLE")) e->presample = atoi(env) != 0;            // (A/B measurements)
+  if (const char *env = getenv("TRG_RESOLVE_TICKETS")) e->resolve_tickets = atoi(env);
   reset_graph_global(e);
   return TRG_OK;
 }
@@ -1975,6 +1981,18 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_lookback_level") {
     e->debug_lookback_level = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "debug_wait_rerun") {
+    e->debug_wait_rerun = v != "0";
+    return TRG_OK;
+  }
+  if (k == "presample") {
+    e->presample = v != "0";
+    return TRG_OK;
+  }
+  if (k == "resolve_tickets") {
+    e->resolve_tickets = atoi(v.c_str());
     return TRG_OK;
   }
   if (k == "tie_inplace") {

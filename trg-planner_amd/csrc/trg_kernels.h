@@ -191,7 +191,8 @@ struct alignas(16) NodeRec {  // per queued node of a level, 48 bytes
   int n_acc, n_draws;         // accepted samples, draws made
   int hits_sample, hits_spec; // map points inside its sampling discs / speculative-edge queries
   unsigned cand_lo, cand_hi;  // bit j: accepted sample j is a candidate
-  int pad[2];
+  int stamp, id;              // set by a p_role workgroup of the previous level's resolve launch: the level tag
+                              // and node id its samples (n_acc, n_draws, hits_sample, slot x y z) belong to
   float px, py, pz;           // the node itself (k_level_spec: its speculative edges start here)
   int pad2;
 };
@@ -228,6 +229,9 @@ struct BfsDev {
   HashEnt *lv_hash;
   int ht_size;
   unsigned long long *wg_state;  // per resolve workgroup: epoch | state | created | valid (look-back scan of the commit)
+  unsigned *ticket;  // start-order tickets of the resolve workgroups (runs on across launches)
+  unsigned long long *front_ready;  // [fcap + 1] handshake words commit -> p_role workgroups: entry b of the next
+                                    // frontier is numbered (tag | creating slot | id); [fcap]: its length
   int4 *nexp;       // per expanded node: accepted | candidates << 8, draws, disc hits, speculative-edge hits
   int *nhits;       // per created node: map points inside its parent edge's queries
   // deferred edge evaluation scratch
@@ -259,7 +263,8 @@ struct FinDev {
 
 void launch_bfs_insert_nodes(const BfsDev &B, int first, int count, hipStream_t s);
 void launch_bfs_clear_tie(const BfsDev &B, hipStream_t s);
-void launch_bfs_undo_commit(const BfsDev &B, int V0, int V1, hipStream_t s);
+// takes the grid reservations of a level's created nodes back (from the slots' outcomes)
+void launch_bfs_undo_slots(const BfsDev &B, int slots, hipStream_t s);
 // ---- one BFS level in three kernels (trg_level.inc) ---------------------------------------------
 constexpr int LEVEL_MAX_SAMPLES = 64;  // sample_num the level kernels support
 // expansion of the frontier nodes [node_base, count) (count_dev != nullptr: count is an upper
@@ -272,9 +277,22 @@ void launch_level_expand(const MapView &m, QueryParams p, const float *cos_t, co
                          DeviceCounters *ctr, hipStream_t s, int which = 3);
 // whether the level kernels can serve these parameters (window of the node grid, sample count)
 bool level_kernels_support(const QueryParams &p, float grid_cell);
-void launch_level_resolve_commit(const BfsDev &B, QueryParams p, int count, int new_state,
+// The pure part of the NEXT level's expansion, run by trailing workgroups of the resolve launch for the
+// frontier entries [0, count) as the commit numbers them (count = 0: none)
+struct LevelNext {
+  void *node_rec = nullptr, *slot_rec = nullptr;  // the next level's record set
+  int count = 0, parity = 0, tag = 0;
+  const float *cos_t = nullptr, *sin_t = nullptr;
+  int table_bits = 0;
+  uint32_t seed = 0, epoch = 0;
+  DeviceCounters *ctr = nullptr;
+};
+// ticketed: the workgroups take their logical index from a start ticket (*B.ticket; ticket_base = tickets
+// drawn by earlier launches, advanced here) instead of blockIdx.x -- the repeat of a launch whose wait ran out
+void launch_level_resolve_commit(const MapView &m, const BfsDev &B, QueryParams p, int count, int new_state,
                                  long long call_base, int V0, int tag, int epoch, hipStream_t s,
-                                 int stall_test);  // 0; test hooks: 1 a candidate stays undecided, 2 a look-back gives up
+                                 int stall_test,  // 0; test hooks: 1 a candidate stays undecided, 2 a look-back gives up
+                                 bool ticketed, unsigned *ticket_base, const LevelNext &next);
 // sums of the per-node expansion statistics into out[0..5] (added to what is there)
 void launch_bfs_stats(const BfsDev &B, int V, unsigned long long *out, hipStream_t s);
 // weights of the edges to the nodes [1, V) the BFS created (covariance -> SVD -> weight)

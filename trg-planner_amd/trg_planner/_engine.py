@@ -72,7 +72,8 @@ class TrgStats(C.Structure):
         ("ms_bfs_loop", C.c_double), ("ms_deferred", C.c_double),
         ("map_nn_resolved", C.c_uint64), ("map_nn_unresolved", C.c_uint64),
         ("bfs_tie_fixups", C.c_uint64), ("bytes_spec_created", C.c_uint64),
-        ("ms_rare_events", C.c_double)]
+        ("ms_rare_events", C.c_double), ("bfs_ticket_reruns", C.c_uint64),
+        ("presampled_nodes", C.c_uint64)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
@@ -94,13 +95,12 @@ EXPORTS = [
 
 def build_library(force=False):
     """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("trg_kernels.hip", "trg_kernels.h", "trg_engine.cpp",
-                                             "host_index.h", "trg_bfs.inc", "trg_bfs_launch.inc",
-                                             "trg_engine_bfs.inc", "trg_voxel.hip",
-                                             "map_order_sim.h", "graph_json.h", "trg_pybind.cpp")]
-    for h in ("trg_engine.h", "trg_shim.hpp"):
-        srcs.append(os.path.normpath(os.path.join(CSRC, "..", "..", "include", h)))
     import glob
+    # every source the build reads: a stale library must never pass for the tree's code
+    srcs = []
+    for pat in ("*.hip", "*.inc", "*.h", "*.cpp", "*.sh"):
+        srcs += glob.glob(os.path.join(CSRC, pat))
+    srcs += glob.glob(os.path.normpath(os.path.join(CSRC, "..", "..", "include", "*")))
     stale = force or not os.path.exists(LIB_PATH) or not glob.glob(os.path.join(_HERE, "_trg_pybind*.so"))
     if not stale:
         t = os.path.getmtime(LIB_PATH)
