@@ -396,11 +396,12 @@ def test_failed_commit_lookback_is_repeated(oa, mountain_small, rerun_fails):
     assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
 
 
-@pytest.mark.parametrize("mode", ["presample_off", "tickets_always"])
+@pytest.mark.parametrize("mode", ["presample_on", "tickets_always"])
 def test_resolve_launch_variants_build_the_same_graph(oa, mountain_small, mode):
-    """The p_role workgroups (pure sampling of the next level inside the resolve launch) and the ticketed
-    workgroup order are optimisations / safety nets: with the first switched off, or the second always
-    on, the graph is the same, and the default build really takes most of its samples from p_role."""
+    """Two variants of the resolve launch must not change the graph: p_role workgroups (the pure sampling
+    of the next level's nodes inside the launch that numbers them; off by default, it measured slower) and
+    start tickets as workgroup indices for every launch (by default only the repeat of a launch whose wait
+    ran out is ticketed)."""
     prm = dict(MOUNTAIN_S16)
     e = _engine(prm)
     e.set_sampler(7, 16)
@@ -408,18 +409,18 @@ def test_resolve_launch_variants_build_the_same_graph(oa, mountain_small, mode):
     e.init_graph([15.0, 15.0, 0.0])
     g0 = e.graph("global")
     st0 = e.stats()
-    assert st0["used_device_bfs"] == 1
-    assert st0["presampled_nodes"] > 0.8 * st0["expanded_nodes"], (st0["presampled_nodes"], st0["expanded_nodes"])
+    assert st0["used_device_bfs"] == 1 and st0["presampled_nodes"] == 0
     e.close()
     e = _engine(prm)
     e.set_sampler(7, 16)
-    e.set_option("presample" if mode == "presample_off" else "resolve_tickets", 0 if mode == "presample_off" else 1)
+    e.set_option("presample" if mode == "presample_on" else "resolve_tickets", 1)
     e.set_global_map(mountain_small)
     e.init_graph([15.0, 15.0, 0.0])
     g1 = e.graph("global")
     st1 = e.stats()
     assert st1["used_device_bfs"] == 1 and st1["bfs_fallbacks"] == 0
-    assert st1["presampled_nodes"] == 0  # (ticketed launches carry no p_role workgroups)
+    if mode == "presample_on":  # the samples of (nearly) every node really came from a p_role workgroup
+        assert st1["presampled_nodes"] > 0.8 * st1["expanded_nodes"], (st1["presampled_nodes"], st1["expanded_nodes"])
     assert_graph_equal(g1, g0, 0.0)
     for k in ("trials", "samples", "created_nodes", "invalid_nodes", "bytes_sample_kernel"):
         assert st0[k] == st1[k], (k, st0[k], st1[k])

@@ -366,7 +366,8 @@ struct TrgEngine {
   int debug_lookback_level = -1; // test hook: one workgroup's commit look-back gives up at this level
   int debug_stall_level = -1;    // test hook: k_level_resolve leaves one candidate of this level undecided
   bool debug_wait_rerun = false; // test hook: the ticketed repeat of that launch runs into the same hook
-  bool presample = true;         // pure part of the next level's expansion inside the resolve launch (p_role workgroups)
+  bool presample = false;        // pure part of the next level's expansion inside the resolve launch (p_role workgroups):
+                                 // measured +3 ms per C3 build (the 8-wave workgroups hold the places the resolve workgroups free)
   int resolve_tickets = 0;       // 1: every resolve launch takes its workgroup indices from start tickets (default: only
                                  // the repeat of a launch whose bounded wait ran out)
   float gate_margin = 1e-4f;     // band in which the slope gate is left to the host's libm

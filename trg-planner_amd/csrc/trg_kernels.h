@@ -226,6 +226,8 @@ struct BfsDev {
   NodeRec *node_rec;
   SlotRec *slot_rec;
   int *c_outcome;   // per slot: resolve outcome (polled across workgroups)
+  unsigned long long *c_cell;  // per slot of the level being resolved, resolve -> commit workgroups: launch epoch << 44 |
+                               // creates a node (0 no, 1 Invalid, 2 valid) << 42 | node-grid cell * GRID_SLOTS + its place
   HashEnt *lv_hash;
   int ht_size;
   unsigned long long *wg_state;  // per resolve workgroup: epoch | state | created | valid (look-back scan of the commit)
@@ -249,6 +251,7 @@ struct BfsDev {
   int *ctrs;
   int *host_ctrs;      // pinned host copy of ctrs + stamp, written by the next level's k_level_sample (may be null)
   unsigned long long *stats64;  // [6]: longest resolve wait; [8..13]: expand phase cycles (profiling)
+  unsigned long long *tl;       // wall-clock marks of a few levels (-DLV_TIMELINE builds with TRG_TIMELINE set; else null)
 };
 
 struct FinDev {
