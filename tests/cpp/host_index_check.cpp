@@ -18,7 +18,7 @@ int main() {
   grid.reset(0, 0, 60, 60, 0.3f);
   okdtree *ref = okd_create();
   std::vector<float> xs, ys;
-  long ties = 0, checked = 0;
+  long ties = 0, checked = 0, multi = 0;
   for (int i = 0; i < 20000; ++i) {
     float x = U(gen), y = U(gen);
     if (i % 9 == 0) {  // lattice points: exact ties
@@ -78,10 +78,32 @@ int main() {
         return 1;
       }
       okd_res_free(rr);
+      // the tree-free way the planner finds the reference's FIRST hit (= reached last by the walk): the
+      // hit set from the grid, the order from kd_range_first_of_two
+      std::vector<int> set;
+      bool doubt = false;
+      grid.range_set(qx, qy, rad, set, &doubt);
+      if (!doubt) {
+        if (set.size() != got.size()) {
+          printf("NodeGrid range_set size mismatch at %d: %zu vs %zu\n", i, set.size(), got.size());
+          return 1;
+        }
+        if (set.size() >= 2) {
+          int last = set[0];
+          for (size_t t = 1; t < set.size(); ++t)
+            if (trg::kd_range_first_of_two(xs.data(), ys.data(), (int)xs.size(), qx, qy, last, set[t]) == last)
+              last = set[t];
+          if (last != got[0]) {
+            printf("range first-hit mismatch at %d: %d vs %d (hits %zu)\n", i, last, got[0], set.size());
+            return 1;
+          }
+          ++multi;
+        }
+      }
     }
     ++checked;
   }
   okd_free(ref);
-  printf("ok checked=%ld ties=%ld\n", checked, ties);
-  return ties > 0 ? 0 : 2;  // the data must actually contain ties
+  printf("ok checked=%ld ties=%ld multi_hit_orders=%ld\n", checked, ties, multi);
+  return (ties > 0 && multi > 100) ? 0 : 2;  // the data must actually contain ties and multi-hit queries
 }

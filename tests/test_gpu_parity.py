@@ -226,6 +226,48 @@ def test_plan_parity(oa, mountain_gentle):
         assert np.array_equal(re_.view(np.uint32), ro.view(np.uint32))
 
 
+def test_plan_on_csr_many_queries(oa, mountain_gentle):
+    """planSafePath runs straight on the CSR; start / goal nodes come from the node grid plus the tree-order
+    arguments (no node tree is built).  200 queries against the oracle, including goals between two or
+    three nodes (several hits within robot_size: the reference takes the one its range walk reaches
+    last), goals exactly on nodes, and goals off the graph (no hit: nearest node in node-map order)."""
+    prm = dict(oa.MOUNTAIN)
+    e, o = _build_both(oa, prm, mountain_gentle, [15.0, 15.0, 0.0], seed=3)
+    g = e.graph("global")
+    rng = np.random.default_rng(11)
+    goals = []
+    for _ in range(60):   # midpoints of edges: both ends are usually within robot_size... or not
+        a = int(rng.integers(0, g.V))
+        if g.rowptr[a + 1] == g.rowptr[a]:
+            continue
+        b = int(g.col[g.rowptr[a] + rng.integers(0, g.rowptr[a + 1] - g.rowptr[a])])
+        goals.append((g.xyz[a] + g.xyz[b]) * np.float32(0.5))
+    for _ in range(40):   # centroids of a node and two of its neighbours
+        a = int(rng.integers(0, g.V))
+        nb = g.col[g.rowptr[a]:g.rowptr[a + 1]]
+        if len(nb) >= 2:
+            goals.append((g.xyz[a] + g.xyz[nb[0]] + g.xyz[nb[1]]) / np.float32(3.0))
+    for _ in range(30):   # exactly on a node
+        goals.append(g.xyz[int(rng.integers(0, g.V))].copy())
+    for _ in range(40):   # anywhere, also outside the map
+        goals.append(np.append(rng.uniform(-5, 35, 2), 0.0).astype(np.float32))
+    multi = 0
+    for k, goal in enumerate(goals):
+        goal = np.asarray(goal, np.float32)
+        d = np.hypot(g.xyz[:, 0] - goal[0], g.xyz[:, 1] - goal[1])
+        multi += int((d < prm["robot_size"]).sum() >= 2)
+        s = rng.uniform(3, 27, 2).astype(np.float32)
+        pe, ie = e.plan(s, goal)
+        po, io = o.plan(s, goal)
+        assert pe.shape == po.shape, (k, pe.shape, po.shape)
+        assert np.array_equal(pe.view(np.uint32), po.view(np.uint32)), k
+        if pe.shape[0]:
+            assert ie.direct_dist == io[0] and ie.path_length == io[1]
+            assert abs(ie.avg_risk - io[2]) <= WEIGHT_TOL
+    assert multi >= 20, multi  # the several-hits branch was really exercised
+    assert e.stats()["used_device_bfs"] == 1
+
+
 def test_plan_batch_equals_consecutive_plans(oa, mountain_gentle):
     """trg_engine_plan_batch = m planSafePath calls in one boundary crossing (the loop over
     start/goal pairs of the reference's run_trg_planner.py:35-43), including a query without a path

@@ -207,6 +207,37 @@ inline int kd_first_of_two(const float *px, const float *py, int K, float qx, fl
   }
 }
 
+// Which of two nodes, both inside the radius of a kd_nearest_range query at (qx, qy), does the walk reach
+// first?  find_nearest (kdtree.c:270-301) tests the node itself, then the subtree on the query's side of
+// the split, then (if |dx| < range) the other one: pre-order, so an ancestor comes before everything
+// below it, and below the lowest common ancestor the near side comes first.  Same single forward scan
+// over the insertion order as kd_first_of_two.  (The result list is filled at its head, kdtree.c:759-777:
+// the reference's FIRST hit is the one reached LAST.)
+inline int kd_range_first_of_two(const float *px, const float *py, int K, float qx, float qy, int A, int B) {
+  if (A == B) return A;
+  const float q[2] = {qx, qy};
+  auto coord = [&](int n, int ax) { return ax == 0 ? px[n] : py[n]; };
+  float lo[2] = {-INFINITY, -INFINITY}, hi[2] = {INFINITY, INFINITY};
+  int cur = 0, axis = 0;
+  for (;;) {
+    if (cur == A || cur == B) return cur;
+    const float split = coord(cur, axis);
+    const bool near_is_left = (q[axis] - split) <= 0;
+    const bool a_left = coord(A, axis) < split, b_left = coord(B, axis) < split;
+    if (a_left != b_left) return (a_left == near_is_left) ? A : B;
+    if (a_left)
+      hi[axis] = split;
+    else
+      lo[axis] = split;
+    axis ^= 1;
+    int n = cur + 1;
+    for (; n < K; ++n)
+      if (px[n] >= lo[0] && px[n] < hi[0] && py[n] >= lo[1] && py[n] < hi[1]) break;
+    if (n >= K) return A < B ? A : B;  // cannot happen: A and B are inside the box
+    cur = n;
+  }
+}
+
 // winner among a set of nodes that all have the minimal squared distance to (qx, qy)
 inline int kd_tie_winner(const float *px, const float *py, int K, float qx, float qy,
                          const std::vector<int> &tied) {
@@ -284,6 +315,30 @@ class NodeGrid {
           if (dd <= hi) doubt = true;
         }
     return doubt ? -1 : 0;
+  }
+
+  // The slots kd_nearest_range2 would report around (qx, qy) (d2 <= r * r), in no particular order.
+  // *doubt: some slot lies within rounding of the radius -- whether the tree walk reaches it depends on
+  // the splits above it (the far side of a split with |dx| >= r is pruned), so the caller asks the tree.
+  void range_set(float qx, float qy, float r, std::vector<int> &out, bool *doubt) const {
+    out.clear();
+    *doubt = false;
+    const float r2 = r * r;
+    const float lo = r2 * (1.0f - 4e-6f), hi = r2 * (1.0f + 4e-6f);
+    const float rad = r * 1.001f + 1e-6f;
+    const int cx0 = clampi((int)std::floor((qx - rad - x0_) * inv_), 0, W_ - 1);
+    const int cx1 = clampi((int)std::floor((qx + rad - x0_) * inv_), 0, W_ - 1);
+    const int cy0 = clampi((int)std::floor((qy - rad - y0_) * inv_), 0, H_ - 1);
+    const int cy1 = clampi((int)std::floor((qy + rad - y0_) * inv_), 0, H_ - 1);
+    for (int yy = cy0; yy <= cy1; ++yy)
+      for (int xx = cx0; xx <= cx1; ++xx)
+        for (int s = head_[(size_t)yy * W_ + xx]; s >= 0; s = next_[s]) {
+          const float dd = dist2(s, qx, qy);
+          if (dd < lo)
+            out.push_back(s);
+          else if (dd <= hi)
+            *doubt = true;
+        }
   }
 
   void insert(float x, float y) {  // slot index == insertion order

@@ -29,6 +29,7 @@
 #include <queue>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -277,6 +278,38 @@ struct TrgEngine;
 namespace {
 TrgStatus stitch_fetch(TrgEngine *e);  // trg_engine_stitch.inc
 }
+// Scratch of one A* search over the CSR.  open_check / close_list of the reference (trg.cpp:619-620,
+// unordered_maps keyed by node id) are flat arrays whose entries count only when their stamp equals the
+// search's generation, so nothing of size V is cleared per query.
+struct PlanScratch {
+  struct Opt {  // OptimizeNode (TRG.h:42-48): f_cost and g_cost are floats
+    int id;
+    int parent;  // index into pool, -1 for the start
+    float f, g;
+  };
+  std::vector<Opt> pool;
+  std::vector<int> heap;
+  std::vector<uint32_t> open_gen, close_gen;
+  std::vector<int> open_idx;
+  uint32_t gen = 0;
+  std::vector<int> chain, hits, tied;
+  void begin(size_t V) {
+    if (open_gen.size() != V) {
+      open_gen.assign(V, 0);
+      close_gen.assign(V, 0);
+      open_idx.assign(V, -1);
+      gen = 0;
+    }
+    if (++gen == 0) {  // wrapped: start over
+      std::fill(open_gen.begin(), open_gen.end(), 0u);
+      std::fill(close_gen.begin(), close_gen.end(), 0u);
+      gen = 1;
+    }
+    pool.clear();
+    heap.clear();
+  }
+};
+
 struct TrgEngine {
   TrgParams prm{};
   int device = 0;
@@ -356,6 +389,13 @@ struct TrgEngine {
   int defer_overlap = 1;         // 1: deferred edge evaluations pipelined behind the level loop on a 2nd stream;
                                  // 2: only the pair-table inserts + first-of-pair selection run beside the loop
                                  // (measured: the loop loses more than the pipeline gains; kept as an option)
+  uint64_t graph_version = 1;    // bumped by everything that changes the global graph (queries cache per version)
+  // planner state (A* runs straight on csr_global, see plan_on_csr): positions in the node tree's insertion
+  // order for the rare order questions (nearest-node ties, several goal hits), and the search scratch
+  std::vector<float> kdo_x, kdo_y;
+  std::vector<int> kdo_index;    // node id -> position in the insertion order
+  uint64_t kdo_version = 0;
+  PlanScratch *plan_scratch = nullptr;
   bool pool_valid = true;        // e->edges mirrors csr_global
   bool host_grid_valid = true;   // e->grid holds the current node set
   bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
@@ -986,6 +1026,7 @@ void reset_graph_global(TrgEngine *e) {
   e->kd_order_dirty = false;
   e->kd_insert_order.clear();
   e->goal_node = -1;
+  e->graph_version++;
 }
 
 // the node map's keys in iteration order, whichever representation is current
@@ -1686,7 +1727,10 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
   {
     int pr_least = 0, pr_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-    HIPCHK(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
+    if (getenv("TRG_MAIN_PRIO") && atoi(getenv("TRG_MAIN_PRIO")) != 0)  // (measurements) the level loop at the highest priority
+      HIPCHK(e, hipStreamCreateWithPriority(&e->s_main, hipStreamNonBlocking, pr_greatest));
+    else
+      HIPCHK(e, hipStreamCreateWithFlags(&e->s_main, hipStreamNonBlocking));
     // TRG_EDGE_CU_MASK=n: the second stream is confined to n compute units (experiment)
     const char *cm = getenv("TRG_EDGE_CU_MASK");
     int ncu_edge = cm ? atoi(cm) : 0;
@@ -1755,6 +1799,7 @@ void trg_engine_destroy(TrgEngine *e) {
     if (e->mt_walk_d) (void)hipFree(e->mt_walk_d);
     if (e->mt_set_h) (void)hipHostFree(e->mt_set_h);
     if (e->mt_walk_h) (void)hipHostFree(e->mt_walk_h);
+    delete e->plan_scratch;
     if (e->bfs) {
       e->bfs->release();
       delete e->bfs;
@@ -1945,6 +1990,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
   if (e->keep_preclean) snapshot_csr(e, e->csr_pre);
   clean_graph(e);
   snapshot_csr(e, e->csr_global);
+  e->graph_version++;
   e->stats.ms_finalize_host = ms_since(t_fin);
   read_counters(e);
   e->stats.ms_init_graph_total = ms_since(t_total);
@@ -2113,6 +2159,7 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   clean_graph(e);
   lap_up("cleanGraph");
   snapshot_csr(e, e->csr_global);
+  e->graph_version++;
   lap_up("CSR snapshot");
   read_counters(e);
   std::vector<int32_t> member_new(e->nx.size(), 0);
@@ -2235,85 +2282,147 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
   e->host_grid_valid = true;
   e->pool_valid = true;
   snapshot_csr(e, e->csr_global);
+  e->graph_version++;
   return TRG_OK;
 }
 
 // ---- planning (host A*, trg.cpp:537-565, 603-690) ------------------------------------------------
-TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goal_xyz[3],
-                          float *path_xyz, int32_t max_points, TrgPathInfo *info) {
-  if (!e || !start_xy || !goal_xyz || !info) return TRG_ERR_INVALID_ARG;
-  info->direct_dist = info->path_length = info->avg_risk = 0.0f;
-  info->num_points = 0;
-  const size_t V = e->nx.size();
-  if (V == 0) return e->fail(TRG_ERR_NO_GRAPH, "graph is empty");
-  ensure_pool(e);
-  kd_sync(e);
+}  // extern "C"
 
-  // setGoal
-  e->goal_pose2d[0] = goal_xyz[0];
-  e->goal_pose2d[1] = goal_xyz[1];
-  std::vector<int> hits;
-  e->kd.range(goal_xyz[0], goal_xyz[1], e->prm.robot_size, hits);
-  if (hits.empty()) {
-    float min_dist = std::numeric_limits<float>::max();
-    std::vector<int> map_order;
-    node_map_order(e, map_order);
-    for (int id : map_order) {
-      const float d = norm2f(e->nx[id] - goal_xyz[0], e->ny[id] - goal_xyz[1]);
-      if (d < min_dist) {
-        min_dist = d;
-        e->goal_node = id;
-      }
-    }
-    e->goal_known = false;
-  } else {
-    e->goal_node = hits[0];
-    e->goal_known = true;
+namespace {
+
+// positions in the node tree's insertion order (cleanGraph refills the tree in the node map's iteration
+// order, trg.cpp:525-530): only built when an answer really hangs on the tree's shape
+void ensure_kd_order_arrays(TrgEngine *e) {
+  if (e->kdo_version == e->graph_version) return;
+  materialize_kd_order(e);
+  const size_t K = e->kd_insert_order.size();
+  e->kdo_x.resize(K);
+  e->kdo_y.resize(K);
+  e->kdo_index.assign(e->nx.size(), -1);
+  for (size_t k = 0; k < K; ++k) {
+    const int id = e->kd_insert_order[k];
+    e->kdo_x[k] = e->nx[id];
+    e->kdo_y[k] = e->ny[id];
+    e->kdo_index[id] = (int)k;
   }
-  const int goal = e->goal_node;
-  const int start = e->kd.nearest(start_xy[0], start_xy[1]);
+  e->kdo_version = e->graph_version;
+}
 
-  struct Opt {
-    int id;
-    int parent;  // index into pool, -1 for the start
-    float f, g;
-  };
-  std::vector<Opt> pool;
+// kd_nearest2 on node_tree (trg.cpp:615): the grid answers; an exact fp32 distance tie goes to the
+// tree-order argument of kd_tie_winner (no tree is built)
+int plan_nearest_node(TrgEngine *e, float qx, float qy, std::vector<int> &tied) {
+  bool tie = false;
+  int s = e->grid.nearest(qx, qy, &tie);
+  if (!tie || s < 0) return s;
+  e->stats.nn_ties++;
+  e->grid.tied_set(qx, qy, e->grid.dist2(s, qx, qy), tied);
+  ensure_kd_order_arrays(e);
+  for (int &t : tied) t = e->kdo_index[t];
+  std::sort(tied.begin(), tied.end());
+  const int w = kd_tie_winner(e->kdo_x.data(), e->kdo_y.data(), (int)e->kdo_x.size(), qx, qy, tied);
+  return e->kd_insert_order[w];
+}
+
+// First item of kd_nearest_range2(node_tree, goal, robot_size) (trg.cpp:544-546), or -1 when the set is
+// empty: the hit set comes from the grid; with several hits the reference takes the one its walk reaches
+// LAST (the result list is filled at the head).  A hit within rounding of the radius sends the question
+// to the tree replica.
+int plan_first_range_hit(TrgEngine *e, float qx, float qy, float r, std::vector<int> &hits) {
+  bool doubt = false;
+  e->grid.range_set(qx, qy, r, hits, &doubt);
+  if (doubt) {
+    kd_sync(e);
+    e->kd.range(qx, qy, r, hits);
+    return hits.empty() ? -1 : hits[0];
+  }
+  if (hits.empty()) return -1;
+  if (hits.size() == 1) return hits[0];
+  ensure_kd_order_arrays(e);
+  const int K = (int)e->kdo_x.size();
+  int last = e->kdo_index[hits[0]];
+  for (size_t i = 1; i < hits.size(); ++i) {
+    const int h = e->kdo_index[hits[i]];
+    if (kd_range_first_of_two(e->kdo_x.data(), e->kdo_y.data(), K, qx, qy, last, h) == last) last = h;
+  }
+  return e->kd_insert_order[last];
+}
+
+// setGoal (trg.cpp:537-565) without side effects: the goal node and whether it lies within robot_size
+void plan_goal_node(TrgEngine *e, PlanScratch &ps, const float goal_xyz[3], int *goal, bool *known) {
+  const int hit = plan_first_range_hit(e, goal_xyz[0], goal_xyz[1], e->prm.robot_size, ps.hits);
+  if (hit >= 0) {
+    *goal = hit;
+    *known = true;
+    return;
+  }
+  // nearest node by the float norm, first in the node map's iteration order among equals (trg.cpp:549-557)
+  float min_dist = std::numeric_limits<float>::max();
+  int g = -1;
+  std::vector<int> map_order;
+  node_map_order(e, map_order);
+  for (int id : map_order) {
+    const float d = norm2f(e->nx[id] - goal_xyz[0], e->ny[id] - goal_xyz[1]);
+    if (d < min_dist) {
+      min_dist = d;
+      g = id;
+    }
+  }
+  *goal = g;
+  *known = false;
+}
+
+// planSafePath (trg.cpp:603-690) on the CSR of the global graph: a row's entries are the node's edges in
+// the reference's push order, the heap is std::push_heap / std::pop_heap with the reference's comparator
+// (f_cost greater-than), so equal-cost ties fall exactly as in the reference's std::priority_queue.
+TrgStatus plan_on_csr(TrgEngine *e, PlanScratch &ps, int start, int goal, float *path_xyz, int32_t max_points,
+                      TrgPathInfo *info) {
+  const Csr &G = e->csr_global;
+  const size_t V = e->nx.size();
+  const int32_t *rowptr = G.rowptr.data(), *col = G.col.data();
+  const float *ew = G.w.data(), *ed = G.dist.data();
+  const float *nx = e->nx.data(), *ny = e->ny.data();
+  const int *nstate = e->nstate.data();
+  ps.begin(V);
+  const uint32_t gen = ps.gen;
+  std::vector<PlanScratch::Opt> &pool = ps.pool;
+  std::vector<int> &heap = ps.heap;
   auto cmp = [&pool](int a, int b) { return pool[a].f > pool[b].f; };
-  std::priority_queue<int, std::vector<int>, std::function<bool(int, int)>> open_list(cmp);
-  std::vector<int> open_check(V, -1), close_list(V, -1);
+  const float gx = nx[goal], gy = ny[goal];
+  const double sf = e->prm.safety_factor;
 
-  info->direct_dist = norm2f(e->nx[goal] - e->nx[start], e->ny[goal] - e->ny[start]);
-  double g_cost = 0.0;
-  double f_cost = g_cost + info->direct_dist;
-  pool.push_back(Opt{start, -1, (float)f_cost, (float)g_cost});
-  open_list.push(0);
-  open_check[start] = 0;
-
-  while (!open_list.empty()) {
-    const int oi = open_list.top();
-    open_list.pop();
-    const Opt cur = pool[oi];
-    open_check[cur.id] = -1;
+  info->direct_dist = norm2f(gx - nx[start], gy - ny[start]);
+  {
+    const double g_cost = 0.0;
+    const double f_cost = g_cost + info->direct_dist;
+    pool.push_back(PlanScratch::Opt{start, -1, (float)f_cost, (float)g_cost});
+    heap.push_back(0);
+    ps.open_gen[start] = gen;
+    ps.open_idx[start] = 0;
+  }
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), cmp);
+    const int oi = heap.back();
+    heap.pop_back();
+    const PlanScratch::Opt cur = pool[oi];
+    ps.open_gen[cur.id] = 0;  // open_check.erase(current id)
 
     if (cur.id == goal) {
-      std::vector<int> chain;
+      std::vector<int> &chain = ps.chain;
+      chain.clear();
       float sum_dist = 0.0, sum_weight = 0.0;
-      int node = oi;
-      while (node >= 0) {
-        const Opt &o = pool[node];
+      for (int node = oi; node >= 0; node = pool[node].parent) {
+        const PlanScratch::Opt &o = pool[node];
         if (o.parent >= 0) {
           const int pid = pool[o.parent].id;
-          for (int ed = e->edges.head[o.id]; ed >= 0; ed = e->edges.next[ed]) {
-            if (e->edges.dst[ed] == pid) {
-              sum_dist += e->edges.dist[ed];
-              sum_weight += e->edges.w[ed];
+          for (int k = rowptr[o.id]; k < rowptr[o.id + 1]; ++k)
+            if (col[k] == pid) {
+              sum_dist += ed[k];
+              sum_weight += ew[k];
               break;
             }
-          }
         }
         chain.push_back(o.id);
-        node = o.parent;
       }
       const float avg_weight = sum_weight / chain.size();
       std::reverse(chain.begin(), chain.end());
@@ -2323,52 +2432,133 @@ TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goa
       if (path_xyz) {
         const int m = std::min<int>((int)chain.size(), max_points);
         for (int i = 0; i < m; ++i) {
-          path_xyz[3 * i] = e->nx[chain[i]];
-          path_xyz[3 * i + 1] = e->ny[chain[i]];
+          path_xyz[3 * i] = nx[chain[i]];
+          path_xyz[3 * i + 1] = ny[chain[i]];
           path_xyz[3 * i + 2] = e->nz[chain[i]];
         }
       }
       return TRG_OK;
     }
 
-    close_list[cur.id] = oi;
-    for (int ed = e->edges.head[cur.id]; ed >= 0; ed = e->edges.next[ed]) {
-      const int dst = e->edges.dst[ed];
+    ps.close_gen[cur.id] = gen;
+    for (int k = rowptr[cur.id]; k < rowptr[cur.id + 1]; ++k) {
+      const int dst = col[k];
       if (dst < 0 || dst >= (int)V) continue;
-      if (close_list[dst] != -1 || e->nstate[dst] == TRG_NODE_INVALID) continue;
-      const double next_g =
-          cur.g + (e->prm.safety_factor * e->edges.w[ed] + 1) * e->edges.dist[ed];
-      const double next_f = next_g + norm2f(e->nx[goal] - e->nx[dst], e->ny[goal] - e->ny[dst]);
-      pool.push_back(Opt{dst, oi, (float)next_f, (float)next_g});
+      if (ps.close_gen[dst] == gen || nstate[dst] == TRG_NODE_INVALID) continue;
+      const double next_g = cur.g + (sf * ew[k] + 1) * ed[k];
+      const double next_f = next_g + norm2f(gx - nx[dst], gy - ny[dst]);
+      pool.push_back(PlanScratch::Opt{dst, oi, (float)next_f, (float)next_g});
       const int ni = (int)pool.size() - 1;
-      if (open_check[dst] == -1) {
-        open_list.push(ni);
-        open_check[dst] = ni;
-      } else if (pool[ni].g < pool[open_check[dst]].g) {
-        open_list.push(ni);
-        open_check[dst] = ni;
+      if (ps.open_gen[dst] != gen || pool[ni].g < pool[ps.open_idx[dst]].g) {
+        heap.push_back(ni);
+        std::push_heap(heap.begin(), heap.end(), cmp);
+        ps.open_gen[dst] = gen;
+        ps.open_idx[dst] = ni;
       }
     }
   }
-  return e->fail(TRG_ERR_NOT_FOUND, "no path");
+  return TRG_ERR_NOT_FOUND;
 }
 
+// common head of plan / plan_batch: graph present, CSR rows and node grid current
+TrgStatus plan_prepare(TrgEngine *e) {
+  const size_t V = e->nx.size();
+  if (V == 0) return e->fail(TRG_ERR_NO_GRAPH, "graph is empty");
+  const Csr &G = e->csr_global;
+  if (G.rowptr.size() != V + 1 || G.state.size() != V) {
+    if (!e->pool_valid) return e->fail(TRG_ERR_NO_GRAPH, "no CSR of the current graph");
+    snapshot_csr(e, e->csr_global);
+  }
+  ensure_host_grid(e);
+  if (!e->plan_scratch) e->plan_scratch = new PlanScratch();
+  return TRG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goal_xyz[3],
+                          float *path_xyz, int32_t max_points, TrgPathInfo *info) {
+  if (!e || !start_xy || !goal_xyz || !info) return TRG_ERR_INVALID_ARG;
+  info->direct_dist = info->path_length = info->avg_risk = 0.0f;
+  info->num_points = 0;
+  TrgStatus st = plan_prepare(e);
+  if (st != TRG_OK) return st;
+  PlanScratch &ps = *e->plan_scratch;
+  // setGoal
+  e->goal_pose2d[0] = goal_xyz[0];
+  e->goal_pose2d[1] = goal_xyz[1];
+  plan_goal_node(e, ps, goal_xyz, &e->goal_node, &e->goal_known);
+  const int start = plan_nearest_node(e, start_xy[0], start_xy[1], ps.tied);
+  st = plan_on_csr(e, ps, start, e->goal_node, path_xyz, max_points, info);
+  if (st == TRG_ERR_NOT_FOUND) return e->fail(TRG_ERR_NOT_FOUND, "no path");
+  return st;
+}
+
+// m consecutive planSafePath calls.  The searches are independent and only read the graph: the start /
+// goal nodes are looked up in call order (the goal state the last call leaves is the reference's), the
+// searches themselves run on up to 8 host threads, each with its own scratch.
 TrgStatus trg_engine_plan_batch(TrgEngine *e, const float *starts_xy, const float *goals_xyz,
                                 size_t m, float *path_xyz, int32_t path_cap, int32_t *offsets,
                                 TrgPathInfo *infos) {
   if (!e || !offsets || (m && (!starts_xy || !goals_xyz || !infos)))
     return TRG_ERR_INVALID_ARG;
   if (path_cap < 0 || (path_cap > 0 && !path_xyz)) return e->fail(TRG_ERR_INVALID_ARG, "path buffer");
-  int32_t used = 0;
   offsets[0] = 0;
+  if (m == 0) return TRG_OK;
+  TrgStatus st = plan_prepare(e);
+  if (st != TRG_OK) return st;
+  PlanScratch &ps0 = *e->plan_scratch;
+  std::vector<int> starts(m), goals(m);
   for (size_t k = 0; k < m; ++k) {
+    infos[k].direct_dist = infos[k].path_length = infos[k].avg_risk = 0.0f;
+    infos[k].num_points = 0;
+    e->goal_pose2d[0] = goals_xyz[3 * k];
+    e->goal_pose2d[1] = goals_xyz[3 * k + 1];
+    plan_goal_node(e, ps0, goals_xyz + 3 * k, &e->goal_node, &e->goal_known);
+    goals[k] = e->goal_node;
+    starts[k] = plan_nearest_node(e, starts_xy[2 * k], starts_xy[2 * k + 1], ps0.tied);
+  }
+  std::vector<std::vector<float>> paths(m);
+  std::vector<TrgStatus> sts(m, TRG_OK);
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t nthr = std::min<size_t>(std::min<size_t>(m, 8), hw);
+  auto work = [&](size_t t, PlanScratch &ps) {
+    for (size_t k = t; k < m; k += nthr) {
+      TrgPathInfo probe;
+      probe.direct_dist = probe.path_length = probe.avg_risk = 0.0f;
+      probe.num_points = 0;
+      sts[k] = plan_on_csr(e, ps, starts[k], goals[k], nullptr, 0, &probe);
+      if (sts[k] == TRG_OK) {
+        paths[k].resize(3 * (size_t)probe.num_points);
+        for (int i = 0; i < probe.num_points; ++i) {
+          const int id = ps.chain[i];
+          paths[k][3 * i] = e->nx[id];
+          paths[k][3 * i + 1] = e->ny[id];
+          paths[k][3 * i + 2] = e->nz[id];
+        }
+      }
+      infos[k] = probe;
+    }
+  };
+  if (nthr <= 1) {
+    work(0, ps0);
+  } else {
+    std::vector<PlanScratch> extra(nthr - 1);
+    std::vector<std::thread> thr;
+    for (size_t t = 1; t < nthr; ++t) thr.emplace_back(work, t, std::ref(extra[t - 1]));
+    work(0, ps0);
+    for (auto &th : thr) th.join();
+  }
+  int32_t used = 0;
+  for (size_t k = 0; k < m; ++k) {
+    if (sts[k] != TRG_OK && sts[k] != TRG_ERR_NOT_FOUND) return e->fail(sts[k], "plan_batch");
+    if (sts[k] == TRG_ERR_NOT_FOUND) infos[k].num_points = 0;
     const int32_t room = path_cap - used;
-    const TrgStatus st = trg_engine_plan(e, starts_xy + 2 * k, goals_xyz + 3 * k,
-                                         path_xyz ? path_xyz + 3 * (size_t)used : nullptr, room,
-                                         &infos[k]);
-    if (st != TRG_OK && st != TRG_ERR_NOT_FOUND) return st;
-    if (st == TRG_ERR_NOT_FOUND) infos[k].num_points = 0;
-    used += std::min<int32_t>(infos[k].num_points, room);
+    const int32_t take = std::min<int32_t>(infos[k].num_points, room);
+    if (take > 0) memcpy(path_xyz + 3 * (size_t)used, paths[k].data(), 3 * (size_t)take * sizeof(float));
+    used += std::max<int32_t>(take, 0);
     offsets[k + 1] = used;
   }
   return TRG_OK;
@@ -2389,11 +2579,16 @@ int32_t trg_engine_check_replan(TrgEngine *e, const float pos_xy[2], const float
   const float dist2subgoal = norm2f(e->nx[g] - pos_xy[0], e->ny[g] - pos_xy[1]);
   if (!e->goal_known && dist2subgoal < e->prm.goal_tolerance) return 1;
   if (!e->goal_known && e->nstate[g] != TRG_NODE_FRONTIER) return 1;
-  kd_sync(e);
+  ensure_host_grid(e);
   std::vector<int> hits;
-  for (int i = 0; i < n_path; ++i) {
-    e->kd.range(path_xyz[3 * i], path_xyz[3 * i + 1], e->prm.robot_size, hits);
-    if (hits.empty()) return 1;
+  for (int i = 0; i < n_path; ++i) {  // (the node grid answers; the tree replica only within rounding of the radius)
+    int w = e->grid.within(path_xyz[3 * i], path_xyz[3 * i + 1], e->prm.robot_size);
+    if (w < 0) {
+      kd_sync(e);
+      e->kd.range(path_xyz[3 * i], path_xyz[3 * i + 1], e->prm.robot_size, hits);
+      w = hits.empty() ? 0 : 1;
+    }
+    if (!w) return 1;
   }
   return 0;
 }
