@@ -10,10 +10,17 @@ summed over all ranks.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, rank == spatial tile of one continuous terrain (weak scaling: every
-rank holds a C3-sized core + halo).  Each rank builds the graph of its core on its GPU; the
-tile-boundary edges are then stitched with two all-gather-v exchanges over RCCL
-(trg_planner/tiled.py; rule and parity oracle: DESIGN.md section 7).
+N > 1: one process per GPU, rank == spatial tile of one continuous terrain.  --scaling weak (default):
+every rank holds a C3-sized core + halo (N x 10 M points); --scaling strong: the ONE C3 cloud is cut
+into the N tiles (BASELINE config 4 = --gpus 4 --scaling strong: the 10 M-point cloud over 2 x 2).
+Each rank builds the graph of its core on its GPU; the tile-boundary edges are then stitched with two
+all-gather-v exchanges over RCCL (trg_planner/tiled.py; rule and parity oracle: DESIGN.md section 7).
+
+Beside the metric the line carries (rank 0): `ms_per_step_incl_upload` (the cloud handed over in pageable
+host memory, as TRG::setGlobalMap gets it), `updates` (--updates K: K setLocalMap + updateGraph steps of
+BASELINE config 5's stream on the built tile, with the CPU oracle's update beside it on the bounded tile),
+and `cpu_baseline` (the oracle on a bounded tile, 3 repetitions, AND on the full workload, one repetition
+in a child process on a core of its own while the GPU part runs).
 """
 import argparse
 import json
@@ -32,9 +39,88 @@ WORKLOADS = {
     "c2": (1000, 1000, 7, "C2: synthetic 1M-pt mountain, mountain.yaml (S=7)"),
     "small": (400, 400, 16, "smoke-size 160k-pt terrain, mountain.yaml, S=16"),
 }
+BOUNDED_N = 1200  # side of the bounded CPU-baseline tile (lattice points)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MOUNTAIN = dict(expand_dist=0.6, robot_size=0.3, height_threshold=0.16, collision_threshold=0.1,
                 update_collision_threshold=0.5, safety_factor=3.0, goal_tolerance=0.8)
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources: a traffic record measured on other kernels must not be quoted"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    c = os.path.join(ROOT, "trg-planner_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(c, "*.hip")) + glob.glob(os.path.join(c, "*.inc")) +
+                    [os.path.join(c, "trg_kernels.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def obs_stream(K, origin_xy, seed, lattice_hi):
+    """BASELINE config 5's stream: K observation clouds = 20 m x 20 m crops (200 x 200 lattice points of
+    the same terrain) around a pose moving 0.5 m per step along a polyline, with three injected obstacles
+    (1.2 m boxes, every second point lifted by 1 m) that make updateGraph invalidate nodes."""
+    from trg_planner import synth
+    for k in range(K):
+        leg, t = divmod(k, 40)
+        dx, dy = ((0.5, 0.2), (0.2, 0.5), (-0.5, 0.2))[leg % 3]
+        base = sum((np.array(((0.5, 0.2), (0.2, 0.5), (-0.5, 0.2))[j % 3]) * 40 for j in range(leg)), np.zeros(2))
+        pose = (float(origin_xy[0] + base[0] + dx * t), float(origin_xy[1] + base[1] + dy * t))
+        ix0 = int(np.clip(round(pose[0] / 0.1) - 100, 0, lattice_hi[0] - 200))
+        iy0 = int(np.clip(round(pose[1] / 0.1) - 100, 0, lattice_hi[1] - 200))
+        obs = synth.mountain_tile(ix0, ix0 + 200, iy0, iy0 + 200, seed=seed)
+        for ox, oy in ((3.0, 1.0), (-4.0, 2.0), (1.0, -5.0)):
+            b = (np.abs(obs[:, 0] - pose[0] - ox) < 0.6) & (np.abs(obs[:, 1] - pose[1] - oy) < 0.6)
+            obs[b, 2] += np.float32(1.0) * (np.arange(int(b.sum())) % 2).astype(np.float32)
+        yield pose, obs
+
+
+def run_updates(target, K, origin_xy, seed, lattice_hi):
+    """K setLocalMap + updateGraph steps on an engine or an oracle (same method names); latencies in ms"""
+    t_map, t_upd, n_obs = [], [], []
+    for pose, obs in obs_stream(K, origin_xy, seed, lattice_hi):
+        t0 = time.perf_counter()
+        target.set_local_map(pose, obs)
+        t1 = time.perf_counter()
+        target.update_graph()
+        t2 = time.perf_counter()
+        t_map.append(1e3 * (t1 - t0))
+        t_upd.append(1e3 * (t2 - t1))
+        n_obs.append(int(obs.shape[0]))
+    if not t_upd:
+        return None
+    return {"updates": K, "obs_points_mean": float(np.mean(n_obs)),
+            "set_local_map_ms_median": float(np.median(t_map)),
+            "update_graph_ms_median": float(np.median(t_upd)),
+            "update_graph_ms_p90": float(np.percentile(t_upd, 90)),
+            "update_graph_ms_max": float(np.max(t_upd))}
+
+
+def oracle_full_child(nx, ny, S, seed, out_path):
+    """Child process (no GPU): the CPU oracle on the FULL workload, one repetition, one core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as oa
+    from trg_planner import synth
+    try:  # a core of its own, far from the CCD the GPU-driving thread is pinned to
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[-1]})
+    except (AttributeError, OSError):
+        pass
+    cloud = synth.mountain_tile(0, nx, 0, ny, seed=seed)
+    used_ref = oa.use_reference_kd(True)
+    o = oa.Oracle(**dict(MOUNTAIN, sample_num=S))
+    o.set_sampler(7, 0, 16)
+    t0 = time.perf_counter()
+    o.set_global_map(cloud)
+    t1 = time.perf_counter()
+    ok = o.init_graph([nx * 0.05, ny * 0.05, 0.0])
+    t2 = time.perf_counter()
+    g = o.graph(0)
+    json.dump({"ok": bool(ok), "V": int(g.V), "E": int(g.E), "index_s": t1 - t0, "init_graph_s": t2 - t1,
+               "value": (g.V + g.E) / (t2 - t0), "points": int(cloud.shape[0]),
+               "kd": "reference kdtree.c (oracle/_ref)" if used_ref else "oracle/okd.c restatement"},
+              open(out_path, "w"))
 
 
 def _host_cpu():
@@ -49,10 +135,11 @@ def _host_cpu():
     return model, cores
 
 
-def cpu_baseline(sample_num, reps=3):
+def cpu_baseline(sample_num, reps=3, updates=0, seed=20250418):
     """The CPU oracle (oracle/, a port of the reference algorithm; its spatial queries run through
     the reference kdtree.c when oracle/_ref is present) timed on this box's host, one core (pinned),
-    on a bounded tile of the same terrain generator / parameters: `reps` repetitions, median."""
+    on a bounded tile of the same terrain generator / parameters: `reps` repetitions, median.  With
+    updates > 0 the last repetition's graph then goes through the same update stream as the engine's."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_api as oa
     from trg_planner import synth
@@ -61,12 +148,13 @@ def cpu_baseline(sample_num, reps=3):
         pinned = True
     except (AttributeError, OSError):
         pinned = False
-    nx = ny = 1200  # 1.44 M points, ~94 k nodes at S=16: about 7 s of single-core work per repetition
-    cloud = synth.mountain_cloud(nx, ny, seed=20250418)
+    nx = ny = BOUNDED_N  # 1.44 M points, ~94 k nodes at S=16: about 7 s of single-core work per repetition
+    cloud = synth.mountain_tile(0, nx, 0, ny, seed=seed)
     used_ref = oa.use_reference_kd(True)
     prm = dict(MOUNTAIN, sample_num=sample_num)
     runs = []
-    for _ in range(reps):
+    upd = None
+    for rep in range(reps):
         o = oa.Oracle(**prm)
         o.set_sampler(7, 0, 16)
         t0 = time.perf_counter()
@@ -77,19 +165,13 @@ def cpu_baseline(sample_num, reps=3):
         g = o.graph(0)
         c = o.counters()
         runs.append(((g.V + g.E) / (t2 - t0), t1 - t0, t2 - t1, g.V, g.E, bool(ok), c["expanded"]))
+        if rep == reps - 1 and updates > 0:
+            upd = run_updates(o, updates, (nx * 0.05 - 20.0, ny * 0.05 - 10.0), seed, (nx, ny))
         o.close()
     oa.use_reference_kd(False)
     runs.sort()
     val, t_index, t_graph, V, E, ok, expanded = runs[len(runs) // 2]
     model, ncpu = _host_cpu()
-    full = None
-    fpath = os.path.join(ROOT, "profiles", "r02_fullscale_parity_c3.json")
-    if os.path.exists(fpath):  # the oracle on the FULL C3 cloud, kept record of the parity run
-        fj = json.load(open(fpath))
-        full = {"index_s": fj["oracle_index_s"], "init_graph_s": fj["oracle_init_graph_s"],
-                "nodes+edges/s": (fj["V_oracle"] + fj["E_oracle"]) /
-                                 (fj["oracle_index_s"] + fj["oracle_init_graph_s"]),
-                "source": os.path.relpath(fpath, ROOT)}
     return {
         "value": val, "unit": "nodes+edges/s", "cores": 1, "kind": "port",
         "sample": (f"bounded sample: {nx}x{ny}={nx * ny} pt tile of the same generator/params "
@@ -100,8 +182,8 @@ def cpu_baseline(sample_num, reps=3):
                    f"{'pinned to one core' if pinned else 'not pinned'}"),
         "host_cpu": model, "host_logical_cpus": ncpu,
         "all_repetitions": [r[0] for r in runs],
-        "full_c3_cloud_record": full,
         "ok": ok, "us_per_expanded_node": 1e6 * t_graph / max(1, expanded),
+        "updates": upd,
     }
 
 
@@ -112,8 +194,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-cpu-baseline", action="store_true",
+                    help="skip the one repetition of the CPU oracle on the full workload (a child process)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank a workload-sized tile; strong = the one cloud cut into N tiles")
+    ap.add_argument("--updates", type=int, default=20,
+                    help="K setLocalMap + updateGraph steps after the timed builds (BASELINE config 5's stream)")
     ap.add_argument("--seed", type=int, default=20250418)
+    ap.add_argument("--oracle-full-child", nargs=4, metavar=("NX", "NY", "S", "OUT"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.oracle_full_child:  # (internal) the CPU oracle on the full workload; never touches the GPU
+        nxc, nyc, Sc, outp = args.oracle_full_child
+        oracle_full_child(int(nxc), int(nyc), int(Sc), args.seed, outp)
+        return
+    rank0_env = int(os.environ.get("RANK", "0")) == 0
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    full_child, full_out = None, None
+    if rank0_env and world_env == 1 and not args.no_cpu_baseline and not args.no_full_cpu_baseline:
+        # started before this process touches the GPU; runs on a core of its own while the GPU part runs
+        import subprocess
+        import tempfile
+        nxw, nyw, Sw, _ = WORKLOADS[args.workload]
+        full_out = os.path.join(tempfile.gettempdir(), f"trg_oracle_full_{os.getpid()}.json")
+        full_child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--seed", str(args.seed),
+                                       "--oracle-full-child", str(nxw), str(nyw), str(Sw), full_out],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -148,13 +253,19 @@ def main():
     # all-gather-v exchanges over RCCL (trg_planner/tiled.py).  N = 1 is the plain single-root build.
     cols, rows = tiling.tile_layout(world)
     halo_pts = 11 if world > 1 else 0
-    core = tiled.tile_cores(cols, rows, nx, ny)[rank]
-    win = tiled.tile_lattice_window(rank, cols, rows, nx, ny, halo_pts)
+    if args.scaling == "strong" and world > 1:
+        # the ONE nx x ny cloud cut into cols x rows tiles (lattice columns / rows split as evenly as they go)
+        core, win = tiled.split_tile(rank, cols, rows, nx, ny, halo_pts)
+        lattice_hi = (nx, ny)
+    else:
+        core = tiled.tile_cores(cols, rows, nx, ny)[rank]
+        win = tiled.tile_lattice_window(rank, cols, rows, nx, ny, halo_pts)
+        lattice_hi = (cols * nx, rows * ny)
     cloud = synth.mountain_tile(*win, seed=args.seed)
     d_cloud = torch.from_numpy(cloud).to(dev)  # inputs resident in HBM before the timed region
     n_pts = cloud.shape[0]
     start = [0.5 * float(core[0] + core[2]), 0.5 * float(core[1] + core[3]), 0.0]
-    del cloud
+    h_cloud = cloud  # (pageable host memory: what TRG::setGlobalMap is handed)
 
     eng = trg_planner.Engine(**dict(MOUNTAIN, sample_num=S), device=local_rank)
     eng.set_sampler(7, 16)
@@ -200,6 +311,33 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    # ---- the same step with the cloud handed over in pageable host memory (setGlobalMap's real input) --------
+    def step_upload():
+        eng.set_global_map(h_cloud)
+        ms_up = eng.stats()["ms_upload"]
+        eng.init_graph(start)
+        return ms_up
+
+    fast = bool(os.environ.get("TRG_BENCH_FAST"))  # (A/B scripts: the metric only)
+    ms_incl_upload, ms_upload_only = None, [0.0]
+    if not fast:
+        step_upload()
+        fence()
+        t0u = time.perf_counter()
+        n_up = max(1, min(args.steps, 5))
+        ms_upload_only = [step_upload() for _ in range(n_up)]
+        fence()
+        ms_incl_upload = 1e3 * (time.perf_counter() - t0u) / n_up
+
+    # ---- BASELINE config 5's update stream on the built tile (rank 0's numbers are reported) -------------------
+    upd_info = None
+    if args.updates > 0 and not fast:
+        upd_info = run_updates(eng, args.updates, (start[0] - 20.0, start[1] - 10.0), args.seed, lattice_hi)
+        if upd_info:
+            Vu, Eu = eng.graph_sizes("global")
+            upd_info.update({"V_after": Vu, "E_after": Eu, "map_points": n_pts})
+        fence()
+
     if os.environ.get("TRG_BENCH_DEBUG"):
         st_dbg = eng.stats()
         sys.stderr.write(f"[bench rank {rank}] used_device_bfs={st_dbg['used_device_bfs']} "
@@ -242,27 +380,39 @@ def main():
         build_gbps = (b_alg_step / 1e9) / (dt / max(1, args.steps))
         # HBM bytes per launch from the separate rocprofv3 --pmc passes of the same workload
         # (profiles/, scripts/profile_gpu.sh; FETCH_SIZE factor as established by scripts/fetch_unit.sh)
-        traffic, traffic_src = None, None
-        for tag in ("r02", "r01"):
+        traffic, traffic_src, traffic_note = None, None, None
+        sha = kernel_source_sha()
+        for tag in ("r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", f"{tag}_{args.workload}_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 parts = dom.split("+")  # kernels timed together: one launch of each per level
-                if all(k in tj for k in parts):
+                if tj.get("kernel_source_sha256") != sha:
+                    traffic_note = (f"{os.path.relpath(tpath, ROOT)} was measured on other kernel sources "
+                                    f"(sha256 {str(tj.get('kernel_source_sha256'))[:12]} != {sha[:12]}): not quoted")
+                elif all(k in tj for k in parts):
                     traffic = sum(tj[k]["hbm_bytes_per_dispatch"] for k in parts)
                     traffic_src = os.path.relpath(tpath, ROOT)
-                    break
+                break
         out = {
             "metric": "TRG nodes+edges built/sec", "value": items / dt, "unit": "nodes+edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_incl_upload": ms_incl_upload,
+            "upload": {"ms_per_step": ms_incl_upload, "ms_upload_median": float(np.median(ms_upload_only)),
+                       "bytes": int(n_pts) * 12,
+                       "note": "the cloud in pageable host memory (numpy), staged through pinned chunks by 4 host "
+                               "threads + hipMemcpyAsync; `value` / `ms_per_step` keep the cloud resident in HBM"},
+            "updates": upd_info,
             "config": {
                 "workload": label, "points_per_gpu": n_pts, "V_prime": V, "E_prime": E,
                 "sampler": "counter-based table, seed 7, 16 bits",
                 "host_thread": ("pinned to CPUs %d-%d of NUMA node %d (the GPU's)" % (pinned[1], pinned[2], pinned[0]))
                 if pinned else "not pinned",
-                "sharding": (f"{cols}x{rows} tiles of one continuous terrain, one per rank, core + "
+                "sharding": (f"{args.scaling} scaling: {cols}x{rows} tiles of one continuous terrain"
+                             f"{' (the ONE workload cloud cut into tiles)' if args.scaling == 'strong' else ' (every tile workload-sized)'}"
+                             f", one per rank, core + "
                              f"1.1 m halo; boundary edges stitched on the GPUs, 2 all-gather-v over "
                              f"{ {'nccl': 'RCCL (device tensors)', 'gloo': 'gloo (host tensors: rehearsal)'}.get(stitch_info['backend'], stitch_info['backend'])} "
                              f"({stitch_info['cross_edges']} cross edges, "
@@ -273,7 +423,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "traffic_note": traffic_note, "kernel_source_sha256": sha,
                 "build_GBps": build_gbps, "build_frac": build_gbps / HBM_PEAK_GBPS,
                 "build_alg_bytes_per_step": b_alg_step,
                 "alg_bytes_per_launch": b / max(1, launches),
@@ -301,8 +451,29 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(S)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(S, updates=min(args.updates, 10), seed=args.seed)
+            cb["bounded_sample_value"] = cb["value"]
+            if full_child is not None:  # the oracle on the FULL workload (child process, one repetition)
+                try:
+                    full_child.wait(timeout=420)
+                    fj = json.load(open(full_out))
+                    os.remove(full_out)
+                    cb["full_workload"] = fj
+                    if fj.get("ok") and fj["V"] == V and fj["E"] == E:
+                        cb["value"] = fj["value"]
+                        cb["sample"] = (f"the FULL workload ({fj['points']} points, S={S}): one repetition measured in this "
+                                        f"run on a host core of its own (index {fj['index_s']:.1f}s + initGraph "
+                                        f"{fj['init_graph_s']:.1f}s, V'={fj['V']} E'={fj['E']} = the GPU build's); "
+                                        f"kd-tree = {fj['kd']}.  Also: " + cb["sample"])
+                except Exception as ex:  # noqa: BLE001  (the bounded sample stands)
+                    full_child.kill()
+                    cb["full_workload"] = {"ok": False, "error": repr(ex)}
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            if upd_info and cb.get("updates"):
+                out["updates"]["cpu_oracle_on_bounded_tile"] = cb["updates"]
+        elif full_child is not None:
+            full_child.kill()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

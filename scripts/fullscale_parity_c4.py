@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Full-size parity run of BASELINE config 4: the 10 M-point C3 cloud cut 2 x 2, every tile built with its
+core restriction, tile-boundary edges stitched -- the engine (four tiles one after the other on ONE GPU,
+native stitch kernels; the collective itself is covered by tests/test_dist_gloo.py) against the tiled CPU
+oracle (tests/tiled_oracle.py rule, oracle/ doing every tile's BFS and every cross edge).  The oracle
+needs ~3 minutes at this size, so it runs HERE, once; the digest of the ORACLE's assembled global graph
+(tests/golden/c4_digest.json + c4_w_sample.npz) is what tests/test_gpu_c4_fullsize.py compares every
+later engine build against.
+
+usage: python scripts/fullscale_parity_c4.py [nx ny cols rows]   (default 3200 3125 2 2)
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "trg-planner_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402,F401  (its ROCm libraries must load before the engine's)
+import oracle_api as oa  # noqa: E402
+import tiled_oracle  # noqa: E402
+import trg_planner  # noqa: E402
+from trg_planner import synth, tiled  # noqa: E402
+
+a = [int(x) for x in sys.argv[1:5]] if len(sys.argv) >= 5 else [3200, 3125, 2, 2]
+nx, ny, cols, rows = a
+HALO, SEED, SSEED = 11, 20250418, 7
+prm = dict(oa.MOUNTAIN, sample_num=16)
+ntiles = cols * rows
+cores, wins = zip(*[tiled.split_tile(t, cols, rows, nx, ny, HALO) for t in range(ntiles)])
+
+# ---- engine: the tiles one after the other, native stitch -------------------------------------------------
+engines = []
+t0 = time.time()
+for t in range(ntiles):
+    cloud = synth.mountain_tile(*wins[t], seed=SEED)
+    e = trg_planner.Engine(**prm)
+    e.set_sampler(SSEED, 16)
+    e.set_tile(cores[t], epoch=t)
+    e.set_global_map(cloud)
+    c = cores[t]
+    e.init_graph([0.5 * float(c[0] + c[2]), 0.5 * float(c[1] + c[3]), 0.0])
+    assert e.stats()["used_device_bfs"] == 1, e.fallback_reason
+    engines.append(e)
+parts, cross = tiled.stitch_emulated(engines, list(cores), cols, rows)
+G = tiled.concat_stitched(parts)
+t_engine = time.time() - t0
+print(f"engine: V={G['V']} E={G['col'].size} cross={cross.shape[0]} in {t_engine:.1f}s (incl. cloud generation)", flush=True)
+
+# ---- tiled CPU oracle ------------------------------------------------------------------------------------
+oa.use_reference_kd(True)
+oracles = []
+t0 = time.time()
+for t in range(ntiles):
+    cloud = synth.mountain_tile(*wins[t], seed=SEED)
+    o = oa.Oracle(**prm)
+    o.set_sampler(SSEED, 0, 16)
+    o.set_tile(cores[t], epoch=t)
+    o.set_global_map(cloud)
+    c = cores[t]
+    assert o.init_graph([0.5 * float(c[0] + c[2]), 0.5 * float(c[1] + c[3]), 0.0]), f"tile {t}: no root"
+    oracles.append(o)
+    print(f"oracle tile {t}: {time.time() - t0:.0f}s", flush=True)
+o_graphs, o_st, OG = tiled_oracle.stitch_oracle(tiled, prm, cols, rows, list(cores), oracles)
+t_oracle = time.time() - t0
+print(f"oracle: V={OG['V']} E={OG['col'].size} cross={o_st[0].shape[0]} in {t_oracle:.1f}s", flush=True)
+
+
+def sha(x, dt):
+    return hashlib.sha256(np.ascontiguousarray(x.astype(dt, copy=False)).tobytes()).hexdigest()
+
+
+same = (G["V"] == OG["V"] and np.array_equal(G["rowptr"], OG["rowptr"]) and np.array_equal(G["col"], OG["col"]) and
+        np.array_equal(G["state"], OG["state"]) and
+        np.array_equal(G["xyz"].view(np.uint32), OG["xyz"].view(np.uint32)) and
+        np.array_equal(G["dist"].view(np.uint32), OG["dist"].view(np.uint32)))
+dw = np.abs(G["w"].astype(np.float64) - OG["w"].astype(np.float64)) if same else np.zeros(0)
+hi = np.maximum(G["w"], OG["w"]) if same else np.zeros(0)
+flip = ((G["w"] == 0) != (OG["w"] == 0)) & (hi >= 0.1 - 1e-5) & (hi <= 0.1 + 1e-5) if same else np.zeros(0, bool)
+res = {"nx": nx, "ny": ny, "layout": [cols, rows], "points_total": int(nx * ny), "engine_s": t_engine,
+       "oracle_s": t_oracle, "structure_bit_equal": bool(same), "V": int(OG["V"]), "E": int(OG["col"].size),
+       "cross_edges": int(o_st[0].shape[0]),
+       "cross_edges_equal": bool(np.array_equal(cross[:, :4], o_st[0])),
+       "weight_max_abs_diff_excl_flips": float(dw[~flip].max()) if same and dw.size else None,
+       "weight_over_1e-5_excl_flips": int((dw[~flip] > 1e-5).sum()) if same else None,
+       "clamp_flips": int(flip.sum()) if same else None}
+print(json.dumps(res, indent=1))
+out = os.path.join(ROOT, "gpurun_out", "golden")
+os.makedirs(out, exist_ok=True)
+rng = np.random.default_rng(SEED)
+E = int(OG["col"].size)
+idx = np.sort(rng.choice(E, size=min(E, 1 << 16), replace=False)).astype(np.int64)
+digest = {
+    "workload": f"C4: synth.mountain_tile lattice {nx}x{ny} (seed {SEED}) cut {cols}x{rows} (tiled.split_tile, halo "
+                f"{HALO} points), mountain.yaml, sampleNum=16, sampler seed {SSEED} / 16 bits / epoch = tile, start = "
+                f"core centre; global graph assembled by the tile rule (DESIGN.md section 7)",
+    "made_by": "scripts/fullscale_parity_c4.py (tests/tiled_oracle.py over oracle/trg_oracle.cpp, kd-tree = reference kdtree.c)",
+    "V": int(OG["V"]), "E": E, "tile_offsets": [int(x) for x in OG["offsets"]], "cross_edges": int(o_st[0].shape[0]),
+    "sha256": {"rowptr": sha(OG["rowptr"], np.int64), "col": sha(OG["col"], np.int64),
+               "state": sha(OG["state"], np.int32), "xyz": sha(OG["xyz"], np.float32),
+               "dist": sha(OG["dist"], np.float32)},
+    "w_zero_edges": int((OG["w"] == 0).sum()), "w_sum": float(OG["w"].astype(np.float64).sum()),
+    "oracle_seconds": t_oracle, "engine_at_digest_time": res,
+}
+json.dump(digest, open(os.path.join(out, "c4_digest.json"), "w"), indent=1)
+np.savez_compressed(os.path.join(out, "c4_w_sample.npz"), idx=idx.astype(np.int32), w=OG["w"][idx].astype(np.float32))
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "fullscale_parity_c4.json"), "w"), indent=1)
+print("digest written to", out)

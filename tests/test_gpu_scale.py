@@ -24,6 +24,45 @@ def _invariants(g, expand_dist):
     assert np.abs(d - g.dist).max() < 1e-5
 
 
+def test_c2_size_against_the_live_oracle(oa, synth):
+    """BASELINE config 2 at its real size (1.0 M points, mountain.yaml, S = 7) against the CPU oracle run
+    right here (about 5 s of host time; its spatial queries through the reference kdtree.c when
+    oracle/_ref is there): structure bit-exact, every weight within 1e-5, and the five planning queries."""
+    import trg_planner
+    from conftest import assert_graph_equal
+    cloud = synth.mountain_tile(0, 1000, 0, 1000, seed=20250418)
+    prm = dict(expand_dist=0.6, robot_size=0.3, sample_num=7, height_threshold=0.16,
+               collision_threshold=0.1, update_collision_threshold=0.5, safety_factor=3.0,
+               goal_tolerance=0.8)
+    e = trg_planner.Engine(**prm)
+    e.set_sampler(7, 16)
+    e.set_global_map(cloud)
+    e.init_graph([50.0, 50.0, 0.0])
+    assert e.stats()["used_device_bfs"] == 1, e.fallback_reason
+    oa.use_reference_kd(True)
+    try:
+        o = oa.Oracle(**prm)
+        o.set_sampler(7, 0, 16)
+        o.set_global_map(cloud)
+        assert o.init_graph([50.0, 50.0, 0.0])
+        g, r = e.graph("global"), o.graph(0)
+        assert g.V > 40000
+        assert_graph_equal(g, r, 1e-5)
+        c, st = o.counters(), e.stats()
+        assert st["trials"] == c["trials"] and st["samples"] == c["samples"]
+        assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
+        rng = np.random.default_rng(1)
+        for _ in range(5):  # start/goal pairs in the style of the reference's run_trg_planner.py:35-43
+            s = rng.uniform(10, 90, 2).astype(np.float32)
+            goal = np.append(rng.uniform(10, 90, 2), 0.0).astype(np.float32)
+            pe, ie = e.plan(s, goal)
+            po, io = o.plan(s, goal)
+            assert np.array_equal(pe.view(np.uint32), po.view(np.uint32))
+            assert ie.path_length == io[1]
+    finally:
+        oa.use_reference_kd(False)
+
+
 def test_c2_size_device_and_host_replay_agree(synth):
     import trg_planner
     cloud = synth.mountain_tile(0, 1000, 0, 1000, seed=20250418)   # 1.0 M points, 100 m x 100 m

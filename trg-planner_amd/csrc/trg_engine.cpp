@@ -271,6 +271,7 @@ struct EdgeBatch {
 
 struct BfsBuffers;  // device-resident BFS state (trg_engine_bfs.inc)
 struct StitchBufs;  // scratch of the tile-boundary stitch (trg_engine_stitch.inc)
+struct Uploader;    // host cloud -> HBM staging (upload_and_build)
 
 }  // namespace
 
@@ -396,6 +397,7 @@ struct TrgEngine {
   std::vector<int> kdo_index;    // node id -> position in the insertion order
   uint64_t kdo_version = 0;
   PlanScratch *plan_scratch = nullptr;
+  Uploader *uploader = nullptr;  // host cloud -> HBM staging (upload_and_build)
   bool pool_valid = true;        // e->edges mirrors csr_global
   bool host_grid_valid = true;   // e->grid holds the current node set
   bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
@@ -615,22 +617,96 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
   return TRG_OK;
 }
 
+// Host cloud -> HBM.  TRG::setGlobalMap / setLocalMap get a cloud in ordinary (pageable) host memory
+// (trg.cpp:179-193, 195-209); a plain hipMemcpy from there runs at a third of the link rate (the runtime
+// stages it through one pinned buffer on one thread: ~25 ms for the 120 MB of C3).  Here UP_THREADS host
+// threads copy interleaved chunks into pinned staging slots of their own and send every chunk on with
+// hipMemcpyAsync on a stream of their own, so the CPU copies and the DMA transfers overlap; a source that
+// is already pinned (hipHostMalloc / hipHostRegister / a pinned torch tensor) goes out in one async copy.
+constexpr int UP_THREADS = 4, UP_SLOTS = 2;
+constexpr size_t UP_CHUNK = (size_t)8 << 20;
+struct Uploader {
+  char *pinned = nullptr;  // UP_THREADS * UP_SLOTS chunks
+  hipStream_t st[UP_THREADS] = {};
+  hipEvent_t ev[UP_THREADS][UP_SLOTS] = {};
+  float *d_in = nullptr;   // device staging of the raw cloud (kept across calls)
+  size_t d_cap = 0;
+  void release() {
+    if (pinned) (void)hipHostFree(pinned);
+    for (auto &s : st)
+      if (s) (void)hipStreamDestroy(s);
+    for (auto &row : ev)
+      for (auto &x : row)
+        if (x) (void)hipEventDestroy(x);
+    if (d_in) (void)hipFree(d_in);
+    *this = Uploader();
+  }
+};
+
+TrgStatus staged_upload(TrgEngine *e, void *d_dst, const void *src, size_t bytes) {
+  Uploader &u = *e->uploader;
+  hipPointerAttribute_t attr;
+  const bool pinned_src = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();  // (an ordinary malloc pointer makes the query fail: not an error)
+  if (pinned_src || bytes < UP_CHUNK) {
+    HIPCHK(e, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, e->s_main));
+    HIPCHK(e, hipStreamSynchronize(e->s_main));
+    return TRG_OK;
+  }
+  if (!u.pinned) {
+    HIPCHK(e, hipHostMalloc((void **)&u.pinned, UP_CHUNK * UP_THREADS * UP_SLOTS, hipHostMallocDefault));
+    for (int t = 0; t < UP_THREADS; ++t) {
+      HIPCHK(e, hipStreamCreateWithFlags(&u.st[t], hipStreamNonBlocking));
+      for (int k = 0; k < UP_SLOTS; ++k) HIPCHK(e, hipEventCreateWithFlags(&u.ev[t][k], hipEventDisableTiming));
+    }
+  }
+  const size_t nchunk = (bytes + UP_CHUNK - 1) / UP_CHUNK;
+  std::atomic<int> bad{0};
+  auto work = [&](int t) {
+    if (hipSetDevice(e->device) != hipSuccess) {
+      bad = 1;
+      return;
+    }
+    int use = 0;
+    for (size_t c = (size_t)t; c < nchunk; c += UP_THREADS, ++use) {
+      const int k = use % UP_SLOTS;
+      char *slot = u.pinned + ((size_t)t * UP_SLOTS + k) * UP_CHUNK;
+      if (use >= UP_SLOTS && hipEventSynchronize(u.ev[t][k]) != hipSuccess) bad = 1;  // the slot's last transfer
+      const size_t off = c * UP_CHUNK, len = std::min(UP_CHUNK, bytes - off);
+      memcpy(slot, (const char *)src + off, len);
+      if (hipMemcpyAsync((char *)d_dst + off, slot, len, hipMemcpyHostToDevice, u.st[t]) != hipSuccess) bad = 1;
+      if (hipEventRecord(u.ev[t][k], u.st[t]) != hipSuccess) bad = 1;
+    }
+    if (hipStreamSynchronize(u.st[t]) != hipSuccess) bad = 1;
+  };
+  std::vector<std::thread> thr;
+  for (int t = 1; t < UP_THREADS; ++t) thr.emplace_back(work, t);
+  work(0);
+  for (auto &th : thr) th.join();
+  if (bad) return e->fail(TRG_ERR_DEVICE, "staged upload of the cloud failed");
+  return TRG_OK;
+}
+
 TrgStatus upload_and_build(TrgEngine *e, DevMap &m, const float *xyz, size_t n, size_t stride) {
   if (n == 0) {
     m.n = 0;
     m.valid = false;
     return TRG_OK;
   }
-  float *d_in = nullptr;
-  HIPCHK(e, hipMalloc((void **)&d_in, n * stride * sizeof(float)));
-  hipError_t he = hipMemcpy(d_in, xyz, n * stride * sizeof(float), hipMemcpyHostToDevice);
-  if (he != hipSuccess) {
-    (void)hipFree(d_in);
-    return e->fail(TRG_ERR_DEVICE, std::string("hipMemcpy map: ") + hipGetErrorString(he));
+  Uploader &u = *e->uploader;
+  const size_t floats = n * stride;
+  if (u.d_cap < floats) {
+    if (u.d_in) (void)hipFree(u.d_in);
+    u.d_in = nullptr;
+    u.d_cap = 0;
+    HIPCHK(e, hipMalloc((void **)&u.d_in, floats * sizeof(float)));
+    u.d_cap = floats;
   }
-  TrgStatus st = build_map(e, m, d_in, n, stride);
-  (void)hipFree(d_in);
-  return st;
+  auto t0 = Clock::now();
+  TrgStatus st = staged_upload(e, u.d_in, xyz, floats * sizeof(float));
+  e->stats.ms_upload = ms_since(t0);
+  if (st != TRG_OK) return st;
+  return build_map(e, m, u.d_in, n, stride);
 }
 
 // ---- sampler table -----------------------------------------------------------------------------
@@ -1755,6 +1831,7 @@ TrgStatus trg_engine_create(const TrgParams *params, int device, TrgEngine **out
   e->device_ok = true;
   e->bfs = new BfsBuffers();
   e->stitch = new StitchBufs();
+  e->uploader = new Uploader();
   if (const char *env = getenv("TRG_REPLAY")) e->use_device_bfs = std::string(env) != "host";
   if (const char *env = getenv("TRG_PRESAMPLE")) e->presample = atoi(env) != 0;            // (A/B measurements)
   if (const char *env = getenv("TRG_RESOLVE_TICKETS")) e->resolve_tickets = atoi(env);
@@ -1800,6 +1877,10 @@ void trg_engine_destroy(TrgEngine *e) {
     if (e->mt_set_h) (void)hipHostFree(e->mt_set_h);
     if (e->mt_walk_h) (void)hipHostFree(e->mt_walk_h);
     delete e->plan_scratch;
+    if (e->uploader) {
+      e->uploader->release();
+      delete e->uploader;
+    }
     if (e->bfs) {
       e->bfs->release();
       delete e->bfs;

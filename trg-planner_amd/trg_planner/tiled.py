@@ -53,6 +53,17 @@ def tile_lattice_window(tile, cols, rows, nx, ny, halo_pts):
     return ix0, ix1, iy0, iy1
 
 
+def split_tile(tile, cols, rows, gx, gy, halo_pts, spacing=0.1):
+    """Strong scaling: ONE gx x gy lattice cut into cols x rows tiles, lattice columns / rows split as
+    evenly as they go.  Returns (core rectangle [x0, y0, x1, y1) fp32, lattice window of core + halo)."""
+    c, r = tile % cols, tile // cols
+    cx0, cx1 = (c * gx) // cols, ((c + 1) * gx) // cols
+    cy0, cy1 = (r * gy) // rows, ((r + 1) * gy) // rows
+    core = np.array([cx0 * spacing, cy0 * spacing, cx1 * spacing, cy1 * spacing], np.float32)
+    win = (max(0, cx0 - halo_pts), min(gx, cx1 + halo_pts), max(0, cy0 - halo_pts), min(gy, cy1 + halo_pts))
+    return core, win
+
+
 def boundary_nodes(xyz, core, cols, rows, tile, dist):
     """Indices of the nodes closer than `dist` to a core side that has a neighbouring tile."""
     c, r = tile % cols, tile // cols
