@@ -414,7 +414,7 @@ def main():
                              f"{' (the ONE workload cloud cut into tiles)' if args.scaling == 'strong' else ' (every tile workload-sized)'}"
                              f", one per rank, core + "
                              f"1.1 m halo; boundary edges stitched on the GPUs, 2 all-gather-v over "
-                             f"{ {'nccl': 'RCCL (device tensors)', 'gloo': 'gloo (host tensors: rehearsal)'}.get(stitch_info['backend'], stitch_info['backend'])} "
+                             f"{ {'nccl': 'RCCL (device tensors)', 'rccl-native': 'RCCL inside the engine (trg_engine_stitch_exchange)', 'gloo': 'gloo (host tensors: rehearsal)'}.get(stitch_info['backend'], stitch_info['backend'])} "
                              f"({stitch_info['cross_edges']} cross edges, "
                              f"{stitch_info['boundary_records']} boundary records); V'/E' = the assembled "
                              f"global graph")

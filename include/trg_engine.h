@@ -295,6 +295,21 @@ TrgStatus trg_engine_stitch_cross(TrgEngine *e, int32_t tile, int32_t ntiles, co
  * result with trg_engine_export_csr(TRG_KIND_STITCHED); creation_id holds the rows' global ids. */
 TrgStatus trg_engine_stitch_assemble(TrgEngine *e, int32_t tile, int32_t ntiles, const int32_t *node_offsets,
                                      const TrgCrossEdge *d_all_edges, int32_t n_edges);
+/* The whole stitch of this rank's tile with both exchanges done natively over RCCL (librccl is resolved at
+ * run time): steps 1-3 above with an all-gather of counts + an all-gather of padded payloads between them.
+ * rank = tile, ranks = cols * rows.  The communicator is either made here from a unique id that ONE rank
+ * draws and the application hands to every rank (MPI_Bcast, a file, torch.distributed ...), or adopted
+ * from the caller (an ncclComm_t of the SAME librccl instance).  A rank whose own step fails announces it
+ * in the next count exchange, so its peers return an error instead of waiting.  Read the result with
+ * trg_engine_export_csr(TRG_KIND_STITCHED).  (Replaces nothing in the reference: TRG has no multi-device
+ * build) */
+#define TRG_COMM_ID_BYTES 128
+TrgStatus trg_engine_comm_unique_id(TrgEngine *e, uint8_t id[TRG_COMM_ID_BYTES]);
+TrgStatus trg_engine_comm_init(TrgEngine *e, const uint8_t id[TRG_COMM_ID_BYTES], int32_t nranks, int32_t rank);
+TrgStatus trg_engine_comm_adopt(TrgEngine *e, void *nccl_comm);
+TrgStatus trg_engine_comm_destroy(TrgEngine *e);
+TrgStatus trg_engine_stitch_exchange(TrgEngine *e, const float core_xyxy[4], int32_t cols, int32_t rows,
+                                     int32_t *n_boundary, int32_t *n_cross);
 /* why the last build fell back from the device path to the host replay ("" if it did not) */
 const char *trg_engine_fallback_reason(const TrgEngine *e);
 

@@ -41,6 +41,26 @@ int main(void) {
   float path[3 * 4096];
   TrgPathInfo info;
   if (trg_engine_plan(e, s2, goal, path, 4096, &info) != TRG_OK || info.num_points < 2) return 7;
+  /* the native stitch exchange as a single-tile "tiling" of one rank: the engine's own RCCL communicator
+   * (unique id drawn here; a multi-process consumer hands the 128 bytes to its peers), all-gathers, assembly */
+  {
+    unsigned char id[TRG_COMM_ID_BYTES];
+    const float core[4] = {-1.0f, -1.0f, 13.0f, 13.0f};
+    int32_t nb = -1, nc = -1;
+    TrgCsrView sg;
+    if (trg_engine_comm_unique_id(e, id) != TRG_OK || trg_engine_comm_init(e, id, 1, 0) != TRG_OK) {
+      fprintf(stderr, "comm: %s\n", trg_engine_last_error(e));
+      return 8;
+    }
+    if (trg_engine_stitch_exchange(e, core, 1, 1, &nb, &nc) != TRG_OK) {
+      fprintf(stderr, "stitch_exchange: %s\n", trg_engine_last_error(e));
+      return 9;
+    }
+    if (nb != 0 || nc != 0) return 10; /* one tile: no shared border */
+    if (trg_engine_export_csr(e, TRG_KIND_STITCHED, &sg) != TRG_OK) return 11;
+    if (sg.num_nodes != g.num_nodes || sg.num_edges != g.num_edges) return 12;
+    trg_engine_comm_destroy(e);
+  }
   TrgStats st;
   trg_engine_get_stats(e, &st);
   printf("ok arch=%s V=%d E=%d path=%d len=%.3f device_bfs=%llu levels=%llu\n",

@@ -1,7 +1,9 @@
 """The N > 1 exchange code over the real backend ("nccl" = RCCL) with ONE rank: the multi-GPU scaling
 run belongs to the driver (no multi-GPU node is available to this build), so this at least runs the very
-calls bench.py --gpus N makes -- process group on the GPU, all-gather of device tensors with ragged sizes,
-the native stitch fed from their results -- on the hardware and backend they will run on."""
+calls bench.py --gpus N makes -- process group on the GPU, the engine's own RCCL communicator (unique id over
+torch.distributed) and trg_engine_stitch_exchange, and the torch.distributed variant of the two exchanges
+(all-gather of device tensors with ragged sizes, the native stitch fed from their results) -- on the hardware
+and backend they will run on."""
 import os
 import subprocess
 import sys
@@ -41,10 +43,22 @@ core = tiled.tile_cores(1, 1, 300, 300)[0]
 eng.set_tile(core, epoch=0)
 eng.set_global_map_device(torch.from_numpy(cloud).to(dev).data_ptr(), cloud.shape[0], 3)
 eng.init_graph([15.0, 15.0, 0.0])
+# the exchanges inside the engine (trg_engine_stitch_exchange on the engine's own RCCL communicator, the
+# unique id carried by torch.distributed) ...
 info = tiled.stitch_device(eng, 0, core, 1, 1, dist)
 V, E = eng.graph_sizes("stitched")
-assert info["backend"] == "nccl" and info["n_cross"] == 0, info
+assert info["backend"] == "rccl-native" and info["n_cross"] == 0, info
 assert (V, E) == tuple(eng.graph_sizes("global")), (V, E)
+g_native = eng.graph("stitched")
+# ... and in torch.distributed (device tensors over the "nccl" backend): the same rows
+os.environ["TRG_NATIVE_EXCHANGE"] = "0"
+info = tiled.stitch_device(eng, 0, core, 1, 1, dist)
+assert info["backend"] == "nccl" and info["n_cross"] == 0, info
+g_torch = eng.graph("stitched")
+for k in ("rowptr", "col", "state", "cid"):
+    assert np.array_equal(getattr(g_native, k), getattr(g_torch, k)), k
+assert np.array_equal(g_native.w.view(np.uint32), g_torch.w.view(np.uint32))
+eng.comm_destroy()
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_WORLD1_OK", V, E)

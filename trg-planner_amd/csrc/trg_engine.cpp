@@ -272,12 +272,14 @@ struct EdgeBatch {
 struct BfsBuffers;  // device-resident BFS state (trg_engine_bfs.inc)
 struct StitchBufs;  // scratch of the tile-boundary stitch (trg_engine_stitch.inc)
 struct Uploader;    // host cloud -> HBM staging (upload_and_build)
+struct ExchangeState;  // RCCL communicator + buffers of the native stitch exchange (trg_engine_exchange.inc)
 
 }  // namespace
 
 struct TrgEngine;
 namespace {
 TrgStatus stitch_fetch(TrgEngine *e);  // trg_engine_stitch.inc
+void exchange_release(TrgEngine *e);   // trg_engine_exchange.inc
 }
 // Scratch of one A* search over the CSR.  open_check / close_list of the reference (trg.cpp:619-620,
 // unordered_maps keyed by node id) are flat arrays whose entries count only when their stamp equals the
@@ -397,7 +399,8 @@ struct TrgEngine {
   std::vector<int> kdo_index;    // node id -> position in the insertion order
   uint64_t kdo_version = 0;
   PlanScratch *plan_scratch = nullptr;
-  Uploader *uploader = nullptr;  // host cloud -> HBM staging (upload_and_build)
+  Uploader *uploader = nullptr;
+  ExchangeState *exchange = nullptr;  // host cloud -> HBM staging (upload_and_build)
   bool pool_valid = true;        // e->edges mirrors csr_global
   bool host_grid_valid = true;   // e->grid holds the current node set
   bool kd_order_dirty = false;   // kd_insert_order must be re-derived from order_map
@@ -1885,6 +1888,7 @@ void trg_engine_destroy(TrgEngine *e) {
       e->bfs->release();
       delete e->bfs;
     }
+    exchange_release(e);
     if (e->stitch) {
       e->stitch->release();
       delete e->stitch;
@@ -2842,3 +2846,4 @@ TrgStatus trg_engine_debug_map_index(TrgEngine *e, TrgKind map, float *x, float 
 }  // extern "C"
 
 #include "trg_engine_stitch.inc"
+#include "trg_engine_exchange.inc"

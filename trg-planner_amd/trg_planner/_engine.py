@@ -90,6 +90,8 @@ EXPORTS = [
     "trg_engine_voxel_filter", "trg_engine_plan_batch",
     "trg_engine_stitch_boundary", "trg_engine_stitch_cross", "trg_engine_stitch_assemble",
     "trg_engine_graph_sizes",
+    "trg_engine_comm_unique_id", "trg_engine_comm_init", "trg_engine_comm_adopt", "trg_engine_comm_destroy",
+    "trg_engine_stitch_exchange",
 ]
 
 
@@ -163,6 +165,12 @@ def load_library():
     L.trg_engine_stitch_cross.argtypes = [vp, C.c_int32, C.c_int32, vp, ip, vp, C.c_int32, ip]
     L.trg_engine_stitch_assemble.argtypes = [vp, C.c_int32, C.c_int32, ip, vp, C.c_int32]
     L.trg_engine_graph_sizes.argtypes = [vp, C.c_int, ip, ip]
+    u8p = C.POINTER(C.c_uint8)
+    L.trg_engine_comm_unique_id.argtypes = [vp, u8p]
+    L.trg_engine_comm_init.argtypes = [vp, u8p, C.c_int32, C.c_int32]
+    L.trg_engine_comm_adopt.argtypes = [vp, vp]
+    L.trg_engine_comm_destroy.argtypes = [vp]
+    L.trg_engine_stitch_exchange.argtypes = [vp, fp, C.c_int32, C.c_int32, ip, ip]
     L.trg_engine_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.trg_engine_fallback_reason.argtypes = [vp]
     L.trg_engine_fallback_reason.restype = C.c_char_p
@@ -261,6 +269,29 @@ class Engine:
         off = np.ascontiguousarray(node_offsets, dtype=np.int32)
         self._chk(self.L.trg_engine_stitch_assemble(self.h, tile, ntiles, _i(off),
                                                     C.c_void_p(all_edges_ptr or 0), n_edges))
+
+    # ---- the native exchange: one call = the whole stitch of this rank's tile over RCCL -------------------
+    def comm_unique_id(self):
+        """128 bytes one rank draws and hands to every rank (e.g. torch.distributed broadcast)."""
+        buf = (C.c_uint8 * 128)()
+        self._chk(self.L.trg_engine_comm_unique_id(self.h, buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, nranks, rank):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.trg_engine_comm_init(self.h, buf, nranks, rank))
+        self._comm_ranks = nranks
+
+    def comm_destroy(self):
+        self.L.trg_engine_comm_destroy(self.h)
+        self._comm_ranks = 0
+
+    def stitch_exchange(self, core_xyxy, cols, rows):
+        """(boundary records of all tiles, cross edges of all tiles); rows: graph('stitched')."""
+        c = np.ascontiguousarray(core_xyxy, dtype=np.float32)
+        nb, nc = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.trg_engine_stitch_exchange(self.h, _f(c), cols, rows, C.byref(nb), C.byref(nc)))
+        return nb.value, nc.value
 
     def set_option(self, key, value):
         self._chk(self.L.trg_engine_set_option(self.h, str(key).encode(), str(value).encode()))

@@ -102,14 +102,37 @@ def allgatherv_t(t, dist=None):
     return torch.cat([o[:c] for o, c in zip(outs, counts)], 0), counts
 
 
+def native_comm(eng, dist):
+    """The engine's own RCCL communicator over the ranks of `dist` (rank == tile): one rank draws the
+    unique id, torch.distributed carries the 128 bytes to the others (any backend), every rank joins.
+    Returns True when the engine now holds a communicator of dist's size."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if getattr(eng, "_comm_ranks", 0) == world:
+        return True
+    ids = [eng.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    eng.comm_init(ids[0], world, rank)
+    return True
+
+
 def stitch_device(eng, my_tile, core, cols, rows, dist=None, gather_dev=None):
     """Steps 2-4 for one rank (rank == tile) with the engine's native stitch (include/trg_engine.h,
     trg_engine_stitch_*): boundary extraction, pair search, cross-edge evaluation and the assembly of
-    this tile's rows of the global graph run on the GPU; the two all-gather-v exchanges carry device
-    tensors (RCCL) -- or host tensors when `gather_dev` is the CPU (gloo rehearsal).
+    this tile's rows of the global graph run on the GPU.  With one rank per GPU the two exchanges run
+    inside the engine as well (trg_engine_stitch_exchange: RCCL all-gathers on the engine's own
+    communicator -- the path a C++ consumer uses; TRG_NATIVE_EXCHANGE=0 keeps the exchanges in
+    torch.distributed); with host tensors (`gather_dev` = CPU: more ranks than GPUs, gloo rehearsal) or
+    without a process group they are torch.distributed all-gathers of padded tensors.
     Returns dict(n_boundary, n_cross, node_offsets, backend)."""
     import torch
     ntiles = cols * rows
+    if (dist is not None and dist.is_initialized() and gather_dev is None and dist.get_world_size() == ntiles
+            and (ntiles > 1 or os.environ.get("TRG_FORCE_COLLECTIVES"))
+            and os.environ.get("TRG_NATIVE_EXCHANGE", "1") != "0" and dist.get_rank() == my_tile):
+        native_comm(eng, dist)
+        nb, nc = eng.stitch_exchange(core, cols, rows)
+        return dict(n_boundary=nb, n_cross=nc, node_offsets=None, backend="rccl-native")
     dev = torch.device("cuda", torch.cuda.current_device())
     gdev = dev if gather_dev is None else gather_dev
     bufs = getattr(eng, "_stitch_bufs", None)  # device scratch kept with the engine, grown on demand
