@@ -781,9 +781,14 @@ DevMap *pick_map(TrgEngine *e, TrgKind k) { return k == TRG_KIND_LOCAL ? &e->lma
 
 // strm: the stream the probe runs in (the main stream may still hold look-ahead work of a finished replay that
 // nobody needs to wait for: the maps are read-only here)
+// radius > 0: probe discs of that radius instead of robot_size (setLocalGraph / isFrontier ask for
+// robot_size / 2, trg.cpp:214, 791) -- passed in the query parameters, the engine's own stay untouched
 TrgStatus collision_sync(TrgEngine *e, DevMap &m, float threshold, const float *xy, size_t cnt,
-                         int32_t *flag, int32_t *c_out, int32_t *n_out, hipStream_t strm = nullptr) {
+                         int32_t *flag, int32_t *c_out, int32_t *n_out, hipStream_t strm = nullptr,
+                         float radius = 0.0f) {
   if (!strm) strm = e->s_main;
+  QueryParams qp = qparams(e);
+  if (radius > 0.0f) qp.robot_size = radius;
   if (!m.valid) {
     // empty map: kd_nearest_range on an empty tree returns no hits -> collision (trg.cpp:749-752)
     for (size_t i = 0; i < cnt; ++i) {
@@ -801,7 +806,7 @@ TrgStatus collision_sync(TrgEngine *e, DevMap &m, float threshold, const float *
     memcpy(e->sy_in.h, xy + 2 * off, m_ * 2 * sizeof(float));
     HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 2 * sizeof(float), hipMemcpyHostToDevice,
                              strm));
-    launch_probe_collision(m.view, qparams(e), threshold, e->sy_in.d, (int)m_, e->sy_i0.d,
+    launch_probe_collision(m.view, qp, threshold, e->sy_in.d, (int)m_, e->sy_i0.d,
                            e->sy_i1.d, e->sy_i2.d, e->d_ctr, strm);
     HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
                              strm));
@@ -1089,6 +1094,13 @@ TrgStatus edges_sync(TrgEngine *e, DevMap &m, const float *p1, const float *p2, 
   return TRG_OK;
 }
 
+// the stitched rows belong to the graph they were assembled from: every change of the global graph voids them
+void invalidate_stitched(TrgEngine *e) {
+  e->stitched_on_device = false;
+  e->stitched_edges = 0;
+  e->csr_stitched.clear();
+}
+
 // ---- graph state helpers -----------------------------------------------------------------------
 void reset_graph_global(TrgEngine *e) {
   e->dev_csr_valid = false;
@@ -1106,6 +1118,7 @@ void reset_graph_global(TrgEngine *e) {
   e->kd_insert_order.clear();
   e->goal_node = -1;
   e->graph_version++;
+  invalidate_stitched(e);
 }
 
 // the node map's keys in iteration order, whichever representation is current
@@ -1720,10 +1733,8 @@ TrgStatus local_membership(TrgEngine *e, std::vector<int32_t> &n) {
     }
   if (cand.empty()) return TRG_OK;
   std::vector<int32_t> nc(cand.size(), 0);
-  TrgParams save = e->prm;
-  e->prm.robot_size = (float)(save.robot_size * 0.5);
-  TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), cand.size(), nullptr, nullptr, nc.data(), e->s_aux);
-  e->prm = save;
+  TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), cand.size(), nullptr, nullptr, nc.data(), e->s_aux,
+                                (float)(e->prm.robot_size * 0.5));
   if (st != TRG_OK) return st;
   for (size_t k = 0; k < cand.size(); ++k) n[cand[k]] = nc[k];
   return TRG_OK;
@@ -2076,6 +2087,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
   clean_graph(e);
   snapshot_csr(e, e->csr_global);
   e->graph_version++;
+  invalidate_stitched(e);
   e->stats.ms_finalize_host = ms_since(t_fin);
   read_counters(e);
   e->stats.ms_init_graph_total = ms_since(t_total);
@@ -2245,6 +2257,7 @@ TrgStatus trg_engine_update_graph(TrgEngine *e) {
   lap_up("cleanGraph");
   snapshot_csr(e, e->csr_global);
   e->graph_version++;
+  invalidate_stitched(e);
   lap_up("CSR snapshot");
   read_counters(e);
   std::vector<int32_t> member_new(e->nx.size(), 0);
@@ -2368,6 +2381,7 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
   e->pool_valid = true;
   snapshot_csr(e, e->csr_global);
   e->graph_version++;
+  invalidate_stitched(e);
   return TRG_OK;
 }
 
@@ -2797,10 +2811,8 @@ TrgStatus trg_engine_is_frontier_batch(TrgEngine *e, const float *xy, size_t m, 
   }
   std::vector<int32_t> n(m, 0);
   if (e->lmap.valid && m) {
-    TrgParams save = e->prm;
-    e->prm.robot_size = (float)(0.5 * save.robot_size);
-    TrgStatus st = collision_sync(e, e->lmap, 0.0f, chk.data(), m, nullptr, nullptr, n.data());
-    e->prm = save;
+    TrgStatus st = collision_sync(e, e->lmap, 0.0f, chk.data(), m, nullptr, nullptr, n.data(), nullptr,
+                                  (float)(0.5 * e->prm.robot_size));
     if (st != TRG_OK) return st;
   }
   for (size_t i = 0; i < m; ++i) flag[i] = (!blocked[i] && n[i] == 0) ? 1 : 0;
