@@ -160,6 +160,7 @@ typedef struct TrgStats {
                                   (map-point ties, uncertain slope gates, node ties, host level replays) */
   uint64_t bfs_ticket_reruns;  /* device path: resolve launches repeated with start tickets as workgroup indices
                                   after a bounded inter-workgroup wait ran out */
+  uint64_t bfs_multipass_rows; /* device path: sample slots whose blockers did not fit one row (taken in passes) */
   double ms_upload;            /* host cloud -> HBM of the last setGlobalMap / setLocalMap from a host pointer */
   uint64_t presampled_nodes;   /* device path: expanded nodes whose samples were already there when their level's
                                   sampling kernel started (drawn inside the previous level's resolve launch) */

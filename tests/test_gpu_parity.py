@@ -510,6 +510,38 @@ def test_device_build_is_deterministic(oa, mountain_gentle):
         assert np.array_equal(np.diff(ge.rowptr)[order_e], np.diff(go.rowptr)[order_o])
 
 
+@pytest.mark.parametrize("S", [48, 64])
+def test_large_sample_num_stays_on_the_device(oa, mountain_gentle, S):
+    """sample_num up to 64 (the level kernels' limit; trg.cpp:387 has none): a slot can have more earlier
+    candidates in reach than its 16-lane row holds at once (64) -- the row then takes them in passes (the
+    hash probed again per pass, the nearest created one carried on) instead of sending the build to the
+    host replay.  Oracle parity, no fallback, repeated builds identical."""
+    prm = dict(oa.MOUNTAIN, sample_num=S)
+    o = oa.Oracle(**prm)
+    o.set_sampler(13, 0, 16)
+    o.set_global_map(mountain_gentle)
+    assert o.init_graph([15.0, 15.0, 0.0])
+    e = _engine(prm)
+    e.set_sampler(13, 16)
+    e.set_option("keep_preclean", 1)
+    e.set_global_map(mountain_gentle)
+    e.init_graph([15.0, 15.0, 0.0])
+    st = e.stats()
+    assert st["used_device_bfs"] == 1 and st["bfs_fallbacks"] == 0, (st["bfs_fallbacks"], e.fallback_reason)
+    if S == 64:
+        assert st["bfs_multipass_rows"] > 0  # the several-passes path really ran
+    assert_graph_equal(e.graph("preclean"), o.graph(1), WEIGHT_TOL)
+    assert_graph_equal(e.graph("global"), o.graph(0), WEIGHT_TOL)
+    c = o.counters()
+    assert st["trials"] == c["trials"] and st["samples"] == c["samples"]
+    assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
+    g0 = e.graph("preclean")
+    for _ in range(2):
+        e.init_graph([15.0, 15.0, 0.0])
+        assert e.stats()["bfs_fallbacks"] == 0
+        assert_graph_equal(e.graph("preclean"), g0, 0.0)
+
+
 @pytest.mark.parametrize("replay", ["device", "host"])
 def test_uncertain_slope_gates_are_decided_by_host_libm(oa, mountain_small, replay):
     """The device calls the slope gate (trg.cpp:269-274) with an exact rational test and leaves a

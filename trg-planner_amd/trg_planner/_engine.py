@@ -73,7 +73,7 @@ class TrgStats(C.Structure):
         ("map_nn_resolved", C.c_uint64), ("map_nn_unresolved", C.c_uint64),
         ("bfs_tie_fixups", C.c_uint64), ("bytes_spec_created", C.c_uint64),
         ("ms_rare_events", C.c_double), ("bfs_ticket_reruns", C.c_uint64),
-        ("ms_upload", C.c_double), ("presampled_nodes", C.c_uint64)]
+        ("bfs_multipass_rows", C.c_uint64), ("ms_upload", C.c_double), ("presampled_nodes", C.c_uint64)]
 
 
 # every symbol include/trg_engine.h declares (tests check that the library exports all of them)
