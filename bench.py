@@ -38,7 +38,13 @@ WORKLOADS = {
     "c3": (3200, 3125, 16, "C3: synthetic 10M-pt Perlin terrain, mountain.yaml, sampleNum(k)=16"),
     "c2": (1000, 1000, 7, "C2: synthetic 1M-pt mountain, mountain.yaml (S=7)"),
     "small": (400, 400, 16, "smoke-size 160k-pt terrain, mountain.yaml, S=16"),
+    # BASELINE config 1: the bundled indoor .pcd is not available offline -- a 40 m x 30 m
+    # floor with 12 wall / box obstacles, voxel filter 0.2 (indoor.yaml), indoor.yaml parameters (step 3 of
+    # expandGraph is ON for these: expand_dist - robot_size < 0.25 expand_dist)
+    "c1": (0, 0, 15, "C1: synthetic indoor stand-in (40 m x 30 m floor, 12 obstacles, 0.1 m), voxel 0.2, indoor.yaml"),
 }
+INDOOR = dict(expand_dist=0.4, robot_size=0.3, height_threshold=0.15, collision_threshold=0.1,
+              update_collision_threshold=0.1, safety_factor=3.0, goal_tolerance=0.8)
 BOUNDED_N = 1200  # side of the bounded CPU-baseline tile (lattice points)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MOUNTAIN = dict(expand_dist=0.6, robot_size=0.3, height_threshold=0.16, collision_threshold=0.1,
@@ -135,7 +141,7 @@ def _host_cpu():
     return model, cores
 
 
-def cpu_baseline(sample_num, reps=3, updates=0, seed=20250418):
+def cpu_baseline(sample_num, reps=3, updates=0, seed=20250418, given=None):
     """The CPU oracle (oracle/, a port of the reference algorithm; its spatial queries run through
     the reference kdtree.c when oracle/_ref is present) timed on this box's host, one core (pinned),
     on a bounded tile of the same terrain generator / parameters: `reps` repetitions, median.  With
@@ -149,9 +155,14 @@ def cpu_baseline(sample_num, reps=3, updates=0, seed=20250418):
     except (AttributeError, OSError):
         pinned = False
     nx = ny = BOUNDED_N  # 1.44 M points, ~94 k nodes at S=16: about 7 s of single-core work per repetition
-    cloud = synth.mountain_tile(0, nx, 0, ny, seed=seed)
-    used_ref = oa.use_reference_kd(True)
+    start = [nx * 0.05, ny * 0.05, 0.0]
     prm = dict(MOUNTAIN, sample_num=sample_num)
+    if given is not None:  # (c1: the workload itself is small enough -- the very cloud, parameters and start)
+        cloud, prm, start = given
+        updates = 0
+    else:
+        cloud = synth.mountain_tile(0, nx, 0, ny, seed=seed)
+    used_ref = oa.use_reference_kd(True)
     runs = []
     upd = None
     for rep in range(reps):
@@ -160,7 +171,7 @@ def cpu_baseline(sample_num, reps=3, updates=0, seed=20250418):
         t0 = time.perf_counter()
         o.set_global_map(cloud)
         t1 = time.perf_counter()
-        ok = o.init_graph([nx * 0.05, ny * 0.05, 0.0])
+        ok = o.init_graph(start)
         t2 = time.perf_counter()
         g = o.graph(0)
         c = o.counters()
@@ -174,7 +185,8 @@ def cpu_baseline(sample_num, reps=3, updates=0, seed=20250418):
     model, ncpu = _host_cpu()
     return {
         "value": val, "unit": "nodes+edges/s", "cores": 1, "kind": "port",
-        "sample": (f"bounded sample: {nx}x{ny}={nx * ny} pt tile of the same generator/params "
+        "sample": ((f"bounded sample: {nx}x{ny}={nx * ny} pt tile of the same generator/params "
+                    if given is None else f"the workload itself ({cloud.shape[0]} points) ") +
                    f"(S={sample_num}), V'={V} E'={E}; median of {reps} repetitions "
                    f"(index {t_index:.2f}s + initGraph {t_graph:.2f}s); TRG logic = oracle/trg_oracle.cpp "
                    f"(port), kd-tree = "
@@ -210,7 +222,8 @@ def main():
     rank0_env = int(os.environ.get("RANK", "0")) == 0
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     full_child, full_out = None, None
-    if rank0_env and world_env == 1 and not args.no_cpu_baseline and not args.no_full_cpu_baseline:
+    if (rank0_env and world_env == 1 and not args.no_cpu_baseline and not args.no_full_cpu_baseline
+            and args.workload != "c1"):
         # started before this process touches the GPU; runs on a core of its own while the GPU part runs
         import subprocess
         import tempfile
@@ -261,13 +274,31 @@ def main():
         core = tiled.tile_cores(cols, rows, nx, ny)[rank]
         win = tiled.tile_lattice_window(rank, cols, rows, nx, ny, halo_pts)
         lattice_hi = (cols * nx, rows * ny)
-    cloud = synth.mountain_tile(*win, seed=args.seed)
+    PRM = MOUNTAIN
+    voxel_info = None
+    if args.workload == "c1":
+        if world > 1:
+            raise SystemExit("--workload c1 is a single-GPU configuration")
+        PRM = INDOOR
+        raw, _ = synth.indoor_cloud(seed=1, size=(40.0, 30.0))
+        pre = trg_planner.Engine(**dict(INDOOR, sample_num=S), device=local_rank)
+        t_v = time.perf_counter()
+        cloud = pre.voxel_filter(raw, 0.2)  # pcl::VoxelGrid of loadPrebuiltMap (trg_planner.cpp:91-94), on the GPU
+        voxel_info = {"points_in": int(raw.shape[0]), "points_out": int(cloud.shape[0]), "leaf": 0.2,
+                      "ms_incl_transfers": 1e3 * (time.perf_counter() - t_v)}
+        pre.close()
+        core = np.array([0.0, 0.0, 40.0, 30.0], np.float32)
+        lattice_hi = (400, 300)
+    else:
+        cloud = synth.mountain_tile(*win, seed=args.seed)
     d_cloud = torch.from_numpy(cloud).to(dev)  # inputs resident in HBM before the timed region
     n_pts = cloud.shape[0]
     start = [0.5 * float(core[0] + core[2]), 0.5 * float(core[1] + core[3]), 0.0]
+    if args.workload == "c1":
+        start = [3.27, 4.12, 0.0]  # the first start of the reference's indoor pairs (run_trg_planner.py:27)
     h_cloud = cloud  # (pageable host memory: what TRG::setGlobalMap is handed)
 
-    eng = trg_planner.Engine(**dict(MOUNTAIN, sample_num=S), device=local_rank)
+    eng = trg_planner.Engine(**dict(PRM, sample_num=S), device=local_rank)
     eng.set_sampler(7, 16)
     if world > 1:
         eng.set_tile(core, epoch=rank)
@@ -331,7 +362,7 @@ def main():
 
     # ---- BASELINE config 5's update stream on the built tile (rank 0's numbers are reported) -------------------
     upd_info = None
-    if args.updates > 0 and not fast:
+    if args.updates > 0 and not fast and args.workload != "c1":
         upd_info = run_updates(eng, args.updates, (start[0] - 20.0, start[1] - 10.0), args.seed, lattice_hi)
         if upd_info:
             Vu, Eu = eng.graph_sizes("global")
@@ -407,6 +438,7 @@ def main():
             "updates": upd_info,
             "config": {
                 "workload": label, "points_per_gpu": n_pts, "V_prime": V, "E_prime": E,
+                "voxel_filter": voxel_info,
                 "sampler": "counter-based table, seed 7, 16 bits",
                 "host_thread": ("pinned to CPUs %d-%d of NUMA node %d (the GPU's)" % (pinned[1], pinned[2], pinned[0]))
                 if pinned else "not pinned",
@@ -451,7 +483,8 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(S, updates=min(args.updates, 10), seed=args.seed)
+            cb = cpu_baseline(S, updates=min(args.updates, 10), seed=args.seed,
+                              given=(h_cloud, dict(PRM, sample_num=S), start) if args.workload == "c1" else None)
             cb["bounded_sample_value"] = cb["value"]
             if full_child is not None:  # the oracle on the FULL workload (child process, one repetition)
                 try:

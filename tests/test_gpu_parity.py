@@ -510,6 +510,29 @@ def test_device_build_is_deterministic(oa, mountain_gentle):
         assert np.array_equal(np.diff(ge.rowptr)[order_e], np.diff(go.rowptr)[order_o])
 
 
+def test_sparse_call_log_builds_the_same_graph(oa, mountain_small):
+    """Builds with expandGraph's step 3 keep LEVEL_STEP3_STRIDE call-log entries per sample slot (the slot's
+    own call, then room for the neighbour calls of the node it creates).  The same layout forced onto a
+    step-3-off configuration must change nothing: graph, statistics, oracle parity."""
+    prm = dict(MOUNTAIN_S16)
+    graphs = []
+    for stride in (0, 1):
+        e = _engine(prm)
+        e.set_sampler(7, 16)
+        e.set_option("keep_preclean", 1)
+        e.set_option("debug_call_stride", stride)
+        e.set_global_map(mountain_small)
+        e.init_graph([15.0, 15.0, 0.0])
+        st = e.stats()
+        assert st["used_device_bfs"] == 1 and st["bfs_fallbacks"] == 0, e.fallback_reason
+        graphs.append((e.graph("preclean"), e.graph("global"), st))
+    assert_graph_equal(graphs[1][0], graphs[0][0], 0.0)
+    assert_graph_equal(graphs[1][1], graphs[0][1], 0.0)
+    for k in ("expanded_nodes", "trials", "samples", "created_nodes", "invalid_nodes", "edge_evals_gpu",
+              "bytes_sample_kernel", "bytes_spec_kernel", "bytes_edge_kernel"):
+        assert graphs[0][2][k] == graphs[1][2][k], k
+
+
 @pytest.mark.parametrize("S", [48, 64])
 def test_large_sample_num_stays_on_the_device(oa, mountain_gentle, S):
     """sample_num up to 64 (the level kernels' limit; trg.cpp:387 has none): a slot can have more earlier

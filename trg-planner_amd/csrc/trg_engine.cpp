@@ -411,6 +411,7 @@ struct TrgEngine {
   int debug_lookback_level = -1; // test hook: one workgroup's commit look-back gives up at this level
   int debug_stall_level = -1;    // test hook: k_level_resolve leaves one candidate of this level undecided
   bool debug_wait_rerun = false; // test hook: the ticketed repeat of that launch runs into the same hook
+  bool debug_call_stride = false; // test hook: the sparse call log of step-3 builds on any configuration
   bool presample = false;        // pure part of the next level's expansion inside the resolve launch (p_role workgroups):
                                  // measured +3 ms per C3 build (the 8-wave workgroups hold the places the resolve workgroups free)
   int resolve_tickets = 0;       // 1: every resolve launch takes its workgroup indices from start tickets (default: only
@@ -2125,6 +2126,10 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_lookback_level") {
     e->debug_lookback_level = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "debug_call_stride") {
+    e->debug_call_stride = v != "0";
     return TRG_OK;
   }
   if (k == "debug_wait_rerun") {

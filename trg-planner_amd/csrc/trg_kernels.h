@@ -247,6 +247,7 @@ struct BfsDev {
   int *call_n1, *call_n2, *call_status;
   float *call_w, *call_dist;
   int *newid_of_call;  // node id created by call number i (set by the commit in k_level_resolve)
+  int cstride;         // call-log entries per sample slot: 1, or LEVEL_STEP3_STRIDE when expandGraph's step 3 is on
   // counters
   int *ctrs;
   int *host_ctrs;      // pinned host copy of ctrs + stamp, written by the next level's k_level_sample (may be null)
@@ -270,6 +271,7 @@ void launch_bfs_clear_tie(const BfsDev &B, hipStream_t s);
 void launch_bfs_undo_slots(const BfsDev &B, int slots, hipStream_t s);
 // ---- one BFS level in three kernels (trg_level.inc) ---------------------------------------------
 constexpr int LEVEL_MAX_SAMPLES = 64;  // sample_num the level kernels support
+constexpr int LEVEL_STEP3_STRIDE = 16; // call-log entries per slot with step 3 on: the slot's own call + up to 15 neighbour calls
 // expansion of the frontier nodes [node_base, count) (count_dev != nullptr: count is an upper
 // bound, the kernel takes min(count, *count_dev)); tag: hash tag of this level attempt (>= 1);
 // pub_stamp != 0: the launch first hands B.ctrs (the counters of the level committed just before
