@@ -57,5 +57,7 @@ def test_indoor_golden(oa):
     e.set_option("keep_preclean", 1)
     e.set_global_map(gold["i_cloud"])
     e.init_graph([1.5, 1.5, 0.0])
+    st = e.stats()  # indoor.yaml turns expandGraph's step 3 on: that runs on the device-resident path too
+    assert st["used_device_bfs"] == 1 and st["bfs_fallbacks"] == 0, e.fallback_reason
     _cmp(e.graph("preclean"), gold, "i_pre")
     _cmp(e.graph("global"), gold, "i_post")

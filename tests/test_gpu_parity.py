@@ -175,9 +175,10 @@ def test_init_graph_parity(oa, request, case, replay):
         start = [1.5, 1.5, 0.0]
     e, o = _build_both(oa, prm, cloud, start, seed=7, replay=replay)
     used_device = e.stats()["used_device_bfs"]
-    # the device-resident BFS serves every config whose expandGraph step 3 is off (trg.cpp:429)
-    assert used_device == (1 if (replay == "device" and not case.startswith("indoor")) else 0), \
-        e.fallback_reason
+    # the device-resident BFS serves both kinds of configuration: expandGraph's step 3 (trg.cpp:429) off
+    # (mountain.yaml) and on (indoor.yaml: rescue search inside the level, neighbour calls after the loop)
+    assert used_device == (1 if replay == "device" else 0), e.fallback_reason
+    assert e.stats()["bfs_fallbacks"] == 0, e.fallback_reason
     pre_e, pre_o = e.graph("preclean"), o.graph(1)
     assert pre_o.V > 200, pre_o.V
     assert_graph_equal(pre_e, pre_o, WEIGHT_TOL)

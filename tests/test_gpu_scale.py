@@ -63,6 +63,44 @@ def test_c2_size_against_the_live_oracle(oa, synth):
         oa.use_reference_kd(False)
 
 
+def test_c1_indoor_standin_against_the_live_oracle(oa, synth):
+    """BASELINE config 1 as bench.py --workload c1 runs it: the 40 m x 30 m indoor stand-in, voxel filter 0.2 on
+    the GPU, indoor.yaml parameters (expandGraph's step 3 ON, trg.cpp:429) -- on the device-resident path, against
+    the CPU oracle run right here (under a second), and against the engine's own sequential host replay."""
+    import trg_planner
+    from conftest import assert_graph_equal
+    raw, _ = synth.indoor_cloud(seed=1, size=(40.0, 30.0))
+    prm = dict(oa.INDOOR)
+    pre = trg_planner.Engine(**prm)
+    cloud = pre.voxel_filter(raw, 0.2)
+    pre.close()
+    start = [3.27, 4.12, 0.0]
+    graphs = {}
+    for mode in ("device", "host"):
+        e = trg_planner.Engine(**prm)
+        e.set_sampler(7, 16)
+        e.set_option("keep_preclean", 1)
+        e.set_option("replay", mode)
+        e.set_global_map(cloud)
+        e.init_graph(start)
+        st = e.stats()
+        assert st["used_device_bfs"] == (1 if mode == "device" else 0) and st["bfs_fallbacks"] == 0, e.fallback_reason
+        graphs[mode] = (e.graph("preclean"), e.graph("global"), st)
+    o = oa.Oracle(**prm)
+    o.set_sampler(7, 0, 16)
+    o.set_global_map(cloud)
+    assert o.init_graph(start)
+    assert o.graph(0).V > 5000
+    for mode in ("device", "host"):
+        assert_graph_equal(graphs[mode][0], o.graph(1), 1e-5)
+        assert_graph_equal(graphs[mode][1], o.graph(0), 1e-5)
+    c = o.counters()
+    st = graphs["device"][2]
+    assert st["trials"] == c["trials"] and st["samples"] == c["samples"]
+    assert st["created_nodes"] == c["created"] and st["invalid_nodes"] == c["invalid_created"]
+    assert c["invalid_created"] > 0  # (nodes whose every call failed exist in this map: the rescue logic had work)
+
+
 def test_c2_size_device_and_host_replay_agree(synth):
     import trg_planner
     cloud = synth.mountain_tile(0, 1000, 0, 1000, seed=20250418)   # 1.0 M points, 100 m x 100 m

@@ -412,6 +412,7 @@ struct TrgEngine {
   int debug_stall_level = -1;    // test hook: k_level_resolve leaves one candidate of this level undecided
   bool debug_wait_rerun = false; // test hook: the ticketed repeat of that launch runs into the same hook
   bool debug_call_stride = false; // test hook: the sparse call log of step-3 builds on any configuration
+  bool step3_device = true;      // configurations with expandGraph's step 3 on the device-resident path too (off: host replay)
   bool presample = false;        // pure part of the next level's expansion inside the resolve launch (p_role workgroups):
                                  // measured +3 ms per C3 build (the 8-wave workgroups hold the places the resolve workgroups free)
   int resolve_tickets = 0;       // 1: every resolve launch takes its workgroup indices from start tickets (default: only
@@ -2010,7 +2011,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
   // (in the main stream: it is non-blocking, a plain memset would not be ordered with the kernels)
   HIPCHK(e, hipMemsetAsync(e->d_ctr, 0, COUNTER_SHARDS * sizeof(DeviceCounters), e->s_main));
   e->lv_hits_sample = e->lv_hits_spec = 0;
-  const bool want_device = !e->step3 && e->use_device_bfs;
+  const bool want_device = e->use_device_bfs && (!e->step3 || e->step3_device);
   if (!want_device) ensure_real_map(e);
   MapOrderSim sim_before;  // container history as of before this build (for the fallback)
   if (want_device) {
@@ -2051,7 +2052,7 @@ TrgStatus trg_engine_init_graph(TrgEngine *e, const float start_xyz[3], const Tr
     cnt++;
   }
 
-  if (!e->step3 && e->use_device_bfs) {
+  if (want_device) {
     st = build_graph_device(e, rx, ry, rz);
     if (st == TRG_OK) {
       read_counters(e);
@@ -2126,6 +2127,10 @@ TrgStatus trg_engine_set_option(TrgEngine *e, const char *key, const char *value
   }
   if (k == "debug_lookback_level") {
     e->debug_lookback_level = atoi(v.c_str());
+    return TRG_OK;
+  }
+  if (k == "step3_device") {
+    e->step3_device = v != "0";
     return TRG_OK;
   }
   if (k == "debug_call_stride") {

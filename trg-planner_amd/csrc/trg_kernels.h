@@ -161,6 +161,8 @@ enum : int {
   BFS_ERR_STALL = 128,  // k_level_resolve's bounded wait ran out: the level is replayed on the host
   BFS_ERR_LOOKBACK = 512,  // the commit's look-back scan ran out of polls (another process on the card): the
                            // level's numbering is void, the whole build is redone by the host replay
+  BFS_ERR_STEP3 = 1024,  // step 3: more neighbours than a list / the call log's stride holds, or a slope gate of a
+                         // rescue edge the device could not call: the build goes to the host replay
   BFS_ERR_TIE_CLS = 256 // a sample's nearest PRE-LEVEL node was not unique (k_level_sample; the slot
                         // carries SLOT_TIE): the host picks the reference's winner, resolve + commit rerun
 };
@@ -203,6 +205,14 @@ struct alignas(16) HashEnt {  // candidate hash of a level: node-grid cell -> ca
   float x, y;
   int pad2[2];
 };
+// expandGraph's step 3 inside a level (trg_step3.inc): who can make a candidate whose parent edge failed a
+// valid node after all.  Per sample slot; written for such candidates only.
+constexpr int RESC_MAX = 14;
+struct alignas(16) RescueRec {
+  int pre;             // 1: an edge to a node that existed before the level succeeds
+  int n;               // earlier candidates of the level whose edge from this sample succeeds ...
+  int slot[RESC_MAX];  // ... their slots
+};
 struct alignas(16) NodeCov {  // what the edge to a node created by the BFS still needs: its weight
   float cov[6];               // is computed after the level loop (k_node_weights)
   int w_given;
@@ -230,6 +240,7 @@ struct BfsDev {
                                // creates a node (0 no, 1 Invalid, 2 valid) << 42 | node-grid cell * GRID_SLOTS + its place
   HashEnt *lv_hash;
   int ht_size;
+  RescueRec *resc;   // step-3 builds only (else null)
   unsigned long long *wg_state;  // per resolve workgroup: epoch | state | created | valid (look-back scan of the commit)
   unsigned *ticket;  // start-order tickets of the resolve workgroups (runs on across launches)
   unsigned long long *front_ready;  // [fcap + 1] handshake words commit -> p_role workgroups: entry b of the next
@@ -299,6 +310,10 @@ void launch_level_resolve_commit(const MapView &m, const BfsDev &B, QueryParams 
                                  int stall_test,  // 0; test hooks: 1 a candidate stays undecided, 2 a look-back gives up
                                  bool ticketed, unsigned *ticket_base, const LevelNext &next);
 // sums of the per-node expansion statistics into out[0..5] (added to what is there)
+typedef int TrgStatus_t;  // 0 ok
+// step 3 after the level loop: the reference's node tree rebuilt on the device (creation order), then the
+// neighbour calls of every valid node into the call log behind its creating call; scratch: 6 V + 8 ints
+TrgStatus_t launch_step3_calls(const BfsDev &B, int V, float range, int *scratch, int *h_left, hipStream_t s);
 void launch_bfs_stats(const BfsDev &B, int V, unsigned long long *out, hipStream_t s);
 // weights of the edges to the nodes [1, V) the BFS created (covariance -> SVD -> weight)
 void launch_node_weights(const BfsDev &B, int V, hipStream_t s);

@@ -2093,6 +2093,7 @@ __global__ __launch_bounds__(SW *WAVE, 8) void k_sample_nodes(MapView m, QueryPa
 
 #include "trg_bfs.inc"
 #include "trg_level.inc"
+#include "trg_step3.inc"
 
 inline int blocks_for(size_t n, int per_block, int cap) {
   size_t b = (n + per_block - 1) / per_block;
