@@ -6,7 +6,7 @@ TAG="${1:-x}"; shift || true
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$R/gpurun_out/ks_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp TRG_BENCH_FAST=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "trace rc=$?"
 cd "$R"

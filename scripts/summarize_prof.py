@@ -73,5 +73,14 @@ if traffic:
         }
         out_j[k]["hbm_bytes_per_dispatch"] = (out_j[k]["fetch_bytes_per_dispatch_corrected"] +
                                               out_j[k]["write_bytes_per_dispatch"])
+    # the record names the kernel sources it was measured on: bench.py quotes it only for these
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trg-planner_amd", "csrc")
+    h = hashlib.sha256()
+    for fsrc in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.inc")) +
+                       [os.path.join(csrc, "trg_kernels.h")]):
+        h.update(os.path.basename(fsrc).encode())
+        h.update(open(fsrc, "rb").read())
+    out_j["kernel_source_sha256"] = h.hexdigest()
     with open(os.path.join(out, "traffic.json"), "w") as fjs:
         json.dump(out_j, fjs, indent=1, sort_keys=True)
