@@ -49,6 +49,21 @@ inline double ms_since(Clock::time_point t0) {
 }
 inline float norm2f(float dx, float dy) { return sqrtf(dx * dx + dy * dy); }
 
+// fn(begin, end) over [0, n) on up to 8 host threads (bulk host passes over the graph: cleanGraph, CSR <-> edge pool)
+template <typename F>
+void parallel_ranges(size_t n, F fn) {
+  const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t T = std::min<size_t>(std::min<size_t>(8, hw), (n + 65535) / 65536);
+  if (T <= 1) {
+    fn((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> thr;
+  for (size_t t = 1; t < T; ++t) thr.emplace_back(fn, n * t / T, n * (t + 1) / T);
+  fn((size_t)0, n / T);
+  for (auto &th : thr) th.join();
+}
+
 struct IndexScratch {  // temporaries of build_index, grown on demand
   int *cell_of = nullptr, *rank = nullptr, *counts = nullptr, *tmp = nullptr;
   void *aos = nullptr;
@@ -85,9 +100,32 @@ struct CallRec {
   float weight, dist;
 };
 
+// std::vector whose resize() leaves trivially constructible elements uninitialised (the bulk builders overwrite
+// every element; value-initialising four 6.7 M-entry arrays cost 10 ms per cleanGraph at C3)
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+  template <typename U>
+  struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  NoInitAlloc() = default;
+  template <typename U>
+  NoInitAlloc(const NoInitAlloc<U> &) {}
+  template <typename U>
+  void construct(U *p) noexcept {
+    ::new ((void *)p) U;
+  }
+  template <typename U, typename... A>
+  void construct(U *p, A &&...a) {
+    ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+template <typename T>
+using RawVec = std::vector<T, NoInitAlloc<T>>;
+
 struct EdgePool {
-  std::vector<int> dst, next;
-  std::vector<float> w, dist;
+  RawVec<int> dst, next;
+  RawVec<float> w, dist;
   std::vector<int> head, tail, deg;
   void reset(size_t nodes) {
     dst.clear();
@@ -109,6 +147,32 @@ struct EdgePool {
     for (int e = head[a]; e >= 0; e = next[e])
       if (dst[e] == b) return true;
     return false;
+  }
+  // rows laid out one after the other (offs[nodes + 1]); the caller fills dst / w / dist of every row and calls
+  // link_rows: the lists then read like pushes in that order, and later pushes append behind them
+  void alloc_rows(const std::vector<int> &offs) {
+    const size_t nodes = offs.size() - 1, E = (size_t)offs[nodes];
+    const size_t room = E + E / 8 + 65536;  // (the pushes that follow must not reallocate 100 MB)
+    dst.reserve(room);
+    next.reserve(room);
+    w.reserve(room);
+    dist.reserve(room);
+    dst.resize(E);
+    next.resize(E);
+    w.resize(E);
+    dist.resize(E);
+    head.resize(nodes);
+    tail.resize(nodes);
+    deg.resize(nodes);
+  }
+  void link_rows(const std::vector<int> &offs, size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
+      const int a = offs[i], b = offs[i + 1];
+      deg[i] = b - a;
+      head[i] = b > a ? a : -1;
+      tail[i] = b > a ? b - 1 : -1;
+      for (int k = a; k < b; ++k) next[k] = k + 1 < b ? k + 1 : -1;
+    }
   }
   void push(int a, int b, float ww, float dd) {
     const int e = (int)dst.size();
@@ -1607,31 +1671,36 @@ void snapshot_csr(const TrgEngine *e, Csr &out) {
   out.cid.resize(V);
   out.rowptr.resize(V + 1);
   out.rowptr[0] = 0;
-  for (size_t i = 0; i < V; ++i) {
-    out.xyz[3 * i] = e->nx[i];
-    out.xyz[3 * i + 1] = e->ny[i];
-    out.xyz[3 * i + 2] = e->nz[i];
-    out.state[i] = e->nstate[i];
-    out.cid[i] = e->ncid[i];
-    out.rowptr[i + 1] = out.rowptr[i] + (i < e->edges.deg.size() ? e->edges.deg[i] : 0);
-  }
+  for (size_t i = 0; i < V; ++i) out.rowptr[i + 1] = out.rowptr[i] + (i < e->edges.deg.size() ? e->edges.deg[i] : 0);
   const size_t E = out.rowptr[V];
   out.col.resize(E);
   out.w.resize(E);
   out.dist.resize(E);
-  for (size_t i = 0; i < V; ++i) {
-    int k = out.rowptr[i];
-    if (i >= e->edges.head.size()) continue;
-    for (int ed = e->edges.head[i]; ed >= 0; ed = e->edges.next[ed]) {
-      out.col[k] = e->edges.dst[ed];
-      out.w[k] = e->edges.w[ed];
-      out.dist[k] = e->edges.dist[ed];
-      ++k;
+  parallel_ranges(V, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
+      out.xyz[3 * i] = e->nx[i];
+      out.xyz[3 * i + 1] = e->ny[i];
+      out.xyz[3 * i + 2] = e->nz[i];
+      out.state[i] = e->nstate[i];
+      out.cid[i] = e->ncid[i];
+      int k = out.rowptr[i];
+      if (i >= e->edges.head.size()) continue;
+      for (int ed = e->edges.head[i]; ed >= 0; ed = e->edges.next[ed]) {
+        out.col[k] = e->edges.dst[ed];
+        out.w[k] = e->edges.w[ed];
+        out.dist[k] = e->edges.dist[ed];
+        ++k;
+      }
     }
-  }
+  });
 }
 
 void clean_graph(TrgEngine *e) {
+  const bool trace = getenv("TRG_TIMING") != nullptr;
+  const auto t_cg = Clock::now();
+  auto lapc = [&](const char *what) {
+    if (trace) fprintf(stderr, "[trg cleanGraph]   %-24s %8.3f ms\n", what, ms_since(t_cg));
+  };
   const size_t V = e->nx.size();
   std::vector<int> old2new(V, 0);  // old2new[] default-constructs 0 in the reference too
   std::vector<int> keep_order;     // old ids in the order they receive new ids
@@ -1648,24 +1717,45 @@ void clean_graph(TrgEngine *e) {
   // trg.cpp:505-520 drops the edges of kept nodes that lead to a node it deletes.  A kept node has edges,
   // so the only deleted nodes an edge can lead to are Invalid ones: "is deleted" is the state test below
   // (no separate marking pass over the 700 k-entry edge pool).
+  lapc("renumbering");
   const int Vn = new_id;
   std::vector<float> x2(Vn), y2(Vn), z2(Vn);
   std::vector<int> st2(Vn), cid2(Vn);
-  EdgePool ep;
-  ep.reset(Vn);
-  for (int k = 0; k < Vn; ++k) {
-    const int old = keep_order[k];
-    x2[k] = e->nx[old];
-    y2[k] = e->ny[old];
-    z2[k] = e->nz[old];
-    st2[k] = e->nstate[old];
-    cid2[k] = e->ncid[old];
-    for (int ed = e->edges.head[old]; ed >= 0; ed = e->edges.next[ed]) {
-      const int d = e->edges.dst[ed];
-      if (e->nstate[d] == TRG_NODE_INVALID) continue;
-      ep.push(k, old2new[d], e->edges.w[ed], e->edges.dist[ed]);
+  // the surviving rows in bulk on several host threads: counts, offsets, then every row copied with its
+  // targets renumbered (a 6.7 M-entry pool rebuilt push by push cost 65 ms per updateGraph at C3)
+  std::vector<int> offs((size_t)Vn + 1, 0);
+  parallel_ranges((size_t)Vn, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
+      const int old = keep_order[k];
+      int n = 0;
+      for (int ed = e->edges.head[old]; ed >= 0; ed = e->edges.next[ed]) n += e->nstate[e->edges.dst[ed]] != TRG_NODE_INVALID;
+      offs[k + 1] = n;
     }
-  }
+  });
+  for (int k = 0; k < Vn; ++k) offs[k + 1] += offs[k];
+  EdgePool ep;
+  ep.alloc_rows(offs);
+  parallel_ranges((size_t)Vn, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
+      const int old = keep_order[k];
+      x2[k] = e->nx[old];
+      y2[k] = e->ny[old];
+      z2[k] = e->nz[old];
+      st2[k] = e->nstate[old];
+      cid2[k] = e->ncid[old];
+      int pos = offs[k];
+      for (int ed = e->edges.head[old]; ed >= 0; ed = e->edges.next[ed]) {
+        const int d = e->edges.dst[ed];
+        if (e->nstate[d] == TRG_NODE_INVALID) continue;
+        ep.dst[pos] = old2new[d];
+        ep.w[pos] = e->edges.w[ed];
+        ep.dist[pos] = e->edges.dist[ed];
+        ++pos;
+      }
+    }
+    ep.link_rows(offs, k0, k1);
+  });
+  lapc("rows copied");
   e->last_new2old = keep_order;
   e->nx.swap(x2);
   e->ny.swap(y2);
@@ -1691,7 +1781,9 @@ void clean_graph(TrgEngine *e) {
   }
   e->kd_order_dirty = false;
   e->kd_valid = false;
+  lapc("container replica");
   grid_rebuild(e);
+  lapc("node grid");
   e->host_grid_valid = true;
   e->pool_valid = true;
 }
@@ -1781,10 +1873,18 @@ void ensure_pool(TrgEngine *e) {
   if (e->pool_valid) return;
   const Csr &g = e->csr_global;
   const size_t V = g.state.size();
-  e->edges.reset(V);
-  e->edges.dst.reserve(g.col.size());
-  for (size_t i = 0; i < V; ++i)
-    for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) e->edges.push((int)i, g.col[k], g.w[k], g.dist[k]);
+  std::vector<int> offs(g.rowptr.data(), g.rowptr.data() + V + 1);
+  e->edges.reset(0);
+  e->edges.alloc_rows(offs);
+  parallel_ranges(V, [&](size_t i0, size_t i1) {
+    const size_t a = (size_t)offs[i0], b = (size_t)offs[i1];
+    if (b > a) {
+      memcpy(e->edges.dst.data() + a, g.col.data() + a, (b - a) * sizeof(int));
+      memcpy(e->edges.w.data() + a, g.w.data() + a, (b - a) * sizeof(float));
+      memcpy(e->edges.dist.data() + a, g.dist.data() + a, (b - a) * sizeof(float));
+    }
+    e->edges.link_rows(offs, i0, i1);
+  });
   e->pool_valid = true;
 }
 void ensure_host_grid(TrgEngine *e) {
