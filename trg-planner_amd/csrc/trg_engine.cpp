@@ -74,6 +74,7 @@ struct DevMap {
   size_t n = 0;
   float *x = nullptr, *y = nullptr, *z = nullptr;
   int *perm = nullptr, *cell_start = nullptr;
+  float4 *pt = nullptr;  // the sorted points as 16-byte records (MapView::pt)
   size_t cap_pts = 0, cap_cells = 0;
   MapView view{};
   float g = 0;
@@ -554,6 +555,7 @@ void free_map(DevMap &m) {
   if (m.y) (void)hipFree(m.y);
   if (m.z) (void)hipFree(m.z);
   if (m.perm) (void)hipFree(m.perm);
+  if (m.pt) (void)hipFree(m.pt);
   if (m.cell_start) (void)hipFree(m.cell_start);
   m = DevMap();
 }
@@ -605,8 +607,11 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
     if (m.y) (void)hipFree(m.y);
     if (m.z) (void)hipFree(m.z);
     if (m.perm) (void)hipFree(m.perm);
+    if (m.pt) (void)hipFree(m.pt);
     m.x = m.y = m.z = nullptr;
     m.perm = nullptr;
+    m.pt = nullptr;
+    HIPCHK(e, hipMalloc((void **)&m.pt, n * sizeof(float4)));
     HIPCHK(e, hipMalloc((void **)&m.x, n * sizeof(float)));
     HIPCHK(e, hipMalloc((void **)&m.y, n * sizeof(float)));
     HIPCHK(e, hipMalloc((void **)&m.z, n * sizeof(float)));
@@ -648,7 +653,7 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
   launch_cell_count(d_xyz, n, stride, x0, y0, inv_g, W, H, d_cell_of, d_rank, d_counts, s);
   launch_exclusive_scan(d_counts, m.cell_start, (int)ncell, d_tmp, s);
   launch_scatter_sort_aos(d_xyz, n, stride, d_cell_of, d_rank, (int)ncell, m.cell_start, sc.aos, m.x, m.y, m.z,
-                          m.perm, s);
+                          m.perm, m.pt, s);
   HIPCHK(e, hipEventRecord(ev1, s));
   HIPCHK(e, hipStreamSynchronize(s));
   HIPCHK(e, hipGetLastError());
@@ -666,6 +671,7 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
   m.view.x = m.x;
   m.view.y = m.y;
   m.view.z = m.z;
+  m.view.pt = m.pt;
   m.view.perm = m.perm;
   m.view.cell_start = m.cell_start;
   m.view.x0 = x0;

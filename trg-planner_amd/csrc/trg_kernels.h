@@ -13,6 +13,8 @@ struct MapView {
   const float *y;
   const float *z;
   const int *perm;        // original index of each sorted point (nearest-neighbour tie-break)
+  const float4 *pt;       // the same points as 16-byte records (x, y, z, perm): what the tile staging reads --
+                          // one load per point, and a row segment's ragged ends cost one partial line, not four
   const int *cell_start;  // W*H + 1 exclusive prefix of points per cell
   float x0, y0;           // grid origin (min x, min y of the cloud)
   float inv_g;            // 1 / cell size
@@ -87,9 +89,10 @@ hipError_t voxel_grid_filter(const float *d_xyz, size_t n, size_t stride, float 
                              size_t *n_out, int *status, hipStream_t s);
 void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, hipStream_t s);
 // scatter + per-cell sort through a scratch array of n 16-byte records (one store per point)
+// (pt: the sorted points once more as 16-byte records, MapView::pt)
 void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
                              const int *d_rank, int ncell, const int *d_cell_start, void *d_aos, float *x,
-                             float *y, float *z, int *perm, hipStream_t s);
+                             float *y, float *z, int *perm, float4 *pt, hipStream_t s);
 
 // ---- queries -----------------------------------------------------------------------------------
 void launch_probe_collision(const MapView &m, QueryParams p, float threshold, const float *d_xy,

@@ -655,9 +655,10 @@ __device__ int stage_tile(const MapView &m, const CellRange &c, WaveTile &t, con
       for (int l = 0; l < nrows; ++l) row += (tq >= __builtin_amdgcn_readlane(inc, l));
       const int src = tq + __shfl(delta, row);
       if (act) {
-        rx[i] = m.x[src];
-        ry[i] = m.y[src];
-        rz[i] = m.z[src];
+        const float4 r = m.pt[src];
+        rx[i] = r.x;
+        ry[i] = r.y;
+        rz[i] = r.z;
       }
     }
   }
@@ -1401,7 +1402,7 @@ __device__ __forceinline__ void cell_insertion_sort(float *x, float *y, float *z
 // written back coalesced (ranges too long for LDS are sorted in place in global memory).
 // (the records k_scatter_aos left are read, the SoA arrays the queries use are written)
 __global__ __launch_bounds__(256) void k_cell_sort_aos(int ncell, const int *cell_start, const float4 *aos,
-                                                       float *x, float *y, float *z, int *perm) {
+                                                       float *x, float *y, float *z, int *perm, float4 *pt) {
   __shared__ float lx[CSORT_CAP], ly[CSORT_CAP], lz[CSORT_CAP];
   __shared__ int lp[CSORT_CAP];
   const int c0 = blockIdx.x * blockDim.x;
@@ -1419,6 +1420,7 @@ __global__ __launch_bounds__(256) void k_cell_sort_aos(int ncell, const int *cel
         perm[i] = __float_as_int(r.w);
       }
       cell_insertion_sort(x, y, z, perm, s0, s1);
+      for (int i = s0; i < s1; ++i) pt[i] = make_float4(x[i], y[i], z[i], __int_as_float(perm[i]));
     }
     return;
   }
@@ -1437,6 +1439,7 @@ __global__ __launch_bounds__(256) void k_cell_sort_aos(int ncell, const int *cel
     y[p0 + i] = ly[i];
     z[p0 + i] = lz[i];
     perm[p0 + i] = lp[i];
+    pt[p0 + i] = make_float4(lx[i], ly[i], lz[i], __int_as_float(lp[i]));
   }
 }
 
@@ -1926,12 +1929,13 @@ __device__ bool stage_sample_tile(const MapView &m, const QueryParams &p, float 
       int row = 0;
       for (int rr = 1; rr < nrows; ++rr) row += (idx >= L.row_off[rr]);
       const int src = L.s_row[row] + (idx - L.row_off[row]);
+      const float4 r = m.pt[src];  // (x, y, z, original index) in one load
       f2 pt;
-      pt.x = m.x[src];
-      pt.y = m.y[src];
+      pt.x = r.x;
+      pt.y = r.y;
       L.xy[idx] = pt;
-      L.z[idx] = m.z[src];
-      L.perm[idx] = m.perm[src];
+      L.z[idx] = r.z;
+      L.perm[idx] = __float_as_int(r.w);
     }
     // cell offsets relative to the tile
     const int ncs = nrows * (ncols + 1);
@@ -2126,11 +2130,11 @@ void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, h
 }
 void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,
                              const int *d_rank, int ncell, const int *d_cell_start, void *d_aos, float *x,
-                             float *y, float *z, int *perm, hipStream_t s) {
+                             float *y, float *z, int *perm, float4 *pt, hipStream_t s) {
   hipLaunchKernelGGL(k_scatter_aos, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, s, d_xyz, n, stride,
                      d_cell_of, d_rank, d_cell_start, (float4 *)d_aos);
   hipLaunchKernelGGL(k_cell_sort_aos, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d_cell_start,
-                     (const float4 *)d_aos, x, y, z, perm);
+                     (const float4 *)d_aos, x, y, z, perm, pt);
 }
 
 void launch_probe_collision(const MapView &m, QueryParams p, float threshold, const float *d_xy,
