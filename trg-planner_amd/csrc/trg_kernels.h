@@ -272,6 +272,7 @@ struct BfsDev {
 struct FinDev {
   unsigned long long *ht_key;
   int *ht_seq;
+  int *ok_seq;  // per table entry: the smallest call number among the pair's SUCCESSFUL calls (its edge)
   unsigned ht_size;
   int *call_slot;
   int *deg, *fill, *rowptr;
