@@ -1089,7 +1089,11 @@ __device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float 
               }
               wave_lds_sync();
             }
-            col = (float)bad / (float)n > p.collision_threshold;
+            // (a flat disc -- most are -- has ratio 0 / n = +0 exactly: no division)
+            if (bad == 0)
+              col = 0.0f > p.collision_threshold;
+            else
+              col = (float)bad / (float)n > p.collision_threshold;
           }
           if (col) {
             o.status = EDGE_SEG | g.uncertain;
