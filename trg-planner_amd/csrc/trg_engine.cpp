@@ -65,9 +65,10 @@ void parallel_ranges(size_t n, F fn) {
 }
 
 struct IndexScratch {  // temporaries of build_index, grown on demand
-  int *cell_of = nullptr, *rank = nullptr, *counts = nullptr, *tmp = nullptr;
+  int *cell_of = nullptr, *rank = nullptr, *counts = nullptr, *tmp = nullptr;  // the direct path (huge grids only)
+  int *hist = nullptr, *base = nullptr, *bin_tmp = nullptr;                    // the path through bins
   void *aos = nullptr;
-  size_t cap_pts = 0, cap_cells = 0;
+  size_t cap_pts = 0, cap_cells = 0, cap_direct = 0, cap_bins = 0;
 };
 
 struct DevMap {
@@ -628,32 +629,56 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
   // a kernel of it)
   IndexScratch &sc = e->idx_scratch;
   if (sc.cap_pts < n) {
-    if (sc.cell_of) (void)hipFree(sc.cell_of);
-    if (sc.rank) (void)hipFree(sc.rank);
     if (sc.aos) (void)hipFree(sc.aos);
-    sc.cell_of = sc.rank = nullptr;
     sc.aos = nullptr;
     sc.cap_pts = 0;
-    HIPCHK(e, hipMalloc((void **)&sc.cell_of, n * sizeof(int)));
-    HIPCHK(e, hipMalloc((void **)&sc.rank, n * sizeof(int)));
     HIPCHK(e, hipMalloc((void **)&sc.aos, n * 16));
     sc.cap_pts = n;
   }
-  if (sc.cap_cells < ncell) {
-    if (sc.counts) (void)hipFree(sc.counts);
-    if (sc.tmp) (void)hipFree(sc.tmp);
-    sc.counts = sc.tmp = nullptr;
-    sc.cap_cells = 0;
-    HIPCHK(e, hipMalloc((void **)&sc.counts, ncell * sizeof(int)));
-    HIPCHK(e, hipMalloc((void **)&sc.tmp, (ncell / 2048 + 4) * sizeof(int)));
-    sc.cap_cells = ncell;
+  int bin_shift = 0, nbins = 0, nwg = 0;
+  if (!getenv("TRG_INDEX_DIRECT") && index_bins_plan(n, ncell, &bin_shift, &nbins, &nwg)) {
+    // through bins of ~one cell row (trg_kernels.hip): no global atomics, no random line per point
+    const size_t nb = (size_t)nbins * nwg;
+    if (sc.cap_bins < nb) {
+      if (sc.hist) (void)hipFree(sc.hist);
+      if (sc.base) (void)hipFree(sc.base);
+      if (sc.bin_tmp) (void)hipFree(sc.bin_tmp);
+      sc.hist = sc.base = sc.bin_tmp = nullptr;
+      sc.cap_bins = 0;
+      HIPCHK(e, hipMalloc((void **)&sc.hist, (nb + 1) * sizeof(int)));
+      HIPCHK(e, hipMalloc((void **)&sc.base, (nb + 1) * sizeof(int)));
+      HIPCHK(e, hipMalloc((void **)&sc.bin_tmp, (nb / 2048 + 4) * sizeof(int)));
+      sc.cap_bins = nb;
+    }
+    // (the map's own record array is the first scratch: it is rewritten by the last kernel)
+    launch_index_bins(d_xyz, n, stride, x0, y0, inv_g, W, H, (int)ncell, bin_shift, nbins, nwg, sc.hist, sc.base,
+                      sc.bin_tmp, m.pt, (float4 *)sc.aos, m.cell_start, m.x, m.y, m.z, m.perm, m.pt, s);
+  } else {
+    if (sc.cap_direct < n) {
+      if (sc.cell_of) (void)hipFree(sc.cell_of);
+      if (sc.rank) (void)hipFree(sc.rank);
+      sc.cell_of = sc.rank = nullptr;
+      sc.cap_direct = 0;
+      HIPCHK(e, hipMalloc((void **)&sc.cell_of, n * sizeof(int)));
+      HIPCHK(e, hipMalloc((void **)&sc.rank, n * sizeof(int)));
+      sc.cap_direct = n;
+    }
+    if (sc.cap_cells < ncell) {
+      if (sc.counts) (void)hipFree(sc.counts);
+      if (sc.tmp) (void)hipFree(sc.tmp);
+      sc.counts = sc.tmp = nullptr;
+      sc.cap_cells = 0;
+      HIPCHK(e, hipMalloc((void **)&sc.counts, ncell * sizeof(int)));
+      HIPCHK(e, hipMalloc((void **)&sc.tmp, (ncell / 2048 + 4) * sizeof(int)));
+      sc.cap_cells = ncell;
+    }
+    int *d_cell_of = sc.cell_of, *d_rank = sc.rank, *d_counts = sc.counts, *d_tmp = sc.tmp;
+    HIPCHK(e, hipMemsetAsync(d_counts, 0, ncell * sizeof(int), s));
+    launch_cell_count(d_xyz, n, stride, x0, y0, inv_g, W, H, d_cell_of, d_rank, d_counts, s);
+    launch_exclusive_scan(d_counts, m.cell_start, (int)ncell, d_tmp, s);
+    launch_scatter_sort_aos(d_xyz, n, stride, d_cell_of, d_rank, (int)ncell, m.cell_start, sc.aos, m.x, m.y, m.z,
+                            m.perm, m.pt, s);
   }
-  int *d_cell_of = sc.cell_of, *d_rank = sc.rank, *d_counts = sc.counts, *d_tmp = sc.tmp;
-  HIPCHK(e, hipMemsetAsync(d_counts, 0, ncell * sizeof(int), s));
-  launch_cell_count(d_xyz, n, stride, x0, y0, inv_g, W, H, d_cell_of, d_rank, d_counts, s);
-  launch_exclusive_scan(d_counts, m.cell_start, (int)ncell, d_tmp, s);
-  launch_scatter_sort_aos(d_xyz, n, stride, d_cell_of, d_rank, (int)ncell, m.cell_start, sc.aos, m.x, m.y, m.z,
-                          m.perm, m.pt, s);
   HIPCHK(e, hipEventRecord(ev1, s));
   HIPCHK(e, hipStreamSynchronize(s));
   HIPCHK(e, hipGetLastError());
@@ -2024,7 +2049,8 @@ void trg_engine_destroy(TrgEngine *e) {
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->d_bounds) (void)hipFree(e->d_bounds);
     for (void *p : {(void *)e->idx_scratch.cell_of, (void *)e->idx_scratch.rank, (void *)e->idx_scratch.counts,
-                    (void *)e->idx_scratch.tmp, e->idx_scratch.aos})
+                    (void *)e->idx_scratch.tmp, e->idx_scratch.aos, (void *)e->idx_scratch.hist,
+                    (void *)e->idx_scratch.base, (void *)e->idx_scratch.bin_tmp})
       if (p) (void)hipFree(p);
     if (e->s_main) (void)hipStreamDestroy(e->s_main);
     if (e->s_edge) (void)hipStreamDestroy(e->s_edge);

@@ -88,6 +88,14 @@ void launch_cell_count(const float *d_xyz, size_t n, size_t stride, float x0, fl
 hipError_t voxel_grid_filter(const float *d_xyz, size_t n, size_t stride, float leaf, float *d_out,
                              size_t *n_out, int *status, hipStream_t s);
 void launch_exclusive_scan(const int *d_counts, int *d_out, int m, int *d_tmp, hipStream_t s);
+// index build through bins (trg_kernels.hip): plan = false when the grid has too many cells for it (the direct
+// count / scatter path then); d_hist and d_base hold nbins * nwg + 1 ints, d_tmp (nbins * nwg) / 2048 + 4,
+// the two scratch arrays n records each (scratch_a may be the map's own record array)
+bool index_bins_plan(size_t n, size_t ncell, int *bin_shift, int *nbins, int *nwg);
+void launch_index_bins(const float *d_xyz, size_t n, size_t stride, float x0, float y0, float inv_g, int W, int H,
+                       int ncell, int bin_shift, int nbins, int nwg, int *d_hist, int *d_base, int *d_tmp,
+                       float4 *d_scratch_a, float4 *d_scratch_b, int *d_cell_start, float *x, float *y, float *z,
+                       int *perm, float4 *pt, hipStream_t s);
 // scatter + per-cell sort through a scratch array of n 16-byte records (one store per point)
 // (pt: the sorted points once more as 16-byte records, MapView::pt)
 void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const int *d_cell_of,

@@ -1392,6 +1392,109 @@ __global__ __launch_bounds__(256) void k_scatter_aos(const float *xyz, size_t n,
   }
 }
 
+// ---- index build through bins (the default) -----------------------------------------------------------
+// The cloud arrives in no order, so counting points per cell with global atomics and scattering them to their
+// cells touches a random line per point (k_cell_count / k_scatter_aos above: 0.74 ms per 10 M points, 5-8 x the
+// bytes they move).  Here the points first go to BINS of 2^bin_shift consecutive cells (about one cell row
+// of the grid, ~9 000 points): every workgroup takes one contiguous chunk of the cloud, counts its points per
+// bin in LDS (k_bin_count), a scan over the (bin, workgroup) counts gives every workgroup a private range in
+// every bin, and the second pass over the chunk writes each point behind its workgroup's cursor (k_bin_scatter:
+// runs of ~36 records).  Then one workgroup per bin counts its points per cell in LDS, scans, writes the
+// bin's part of cell_start and places the points (k_bin_cells: all atomics in LDS, all traffic inside a
+// 150-KB range).  k_cell_sort_aos finishes as before (cells ordered by original index, SoA + records).
+constexpr int BIN_WG = 256;            // chunks of the cloud = workgroups of the two binning passes
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_MAX = 4096;          // bins an LDS histogram holds
+constexpr int BIN_CELLS_MAX = 8192;    // cells of one bin (their counters live in LDS)
+constexpr int BIN_CELL_THREADS = 512;
+
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const float *xyz, size_t n, size_t stride, float x0,
+                                                           float y0, float inv_g, int W, int H, int bin_shift,
+                                                           int nbins, size_t chunk, int *hist) {
+  __shared__ int h[BIN_MAX];
+  for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) h[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+  for (size_t i = lo + threadIdx.x; i < hi; i += BIN_THREADS) {
+    const int cx = cell_coord(xyz[i * stride], x0, inv_g, W);
+    const int cy = cell_coord(xyz[i * stride + 1], y0, inv_g, H);
+    atomicAdd(&h[(cy * W + cx) >> bin_shift], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) hist[(size_t)b * gridDim.x + blockIdx.x] = h[b];
+}
+
+// base = exclusive scan of hist: where this workgroup's points of bin b start
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const float *xyz, size_t n, size_t stride, float x0,
+                                                             float y0, float inv_g, int W, int H, int bin_shift,
+                                                             int nbins, size_t chunk, const int *base,
+                                                             float4 *out) {
+  __shared__ int cur[BIN_MAX];
+  for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) cur[b] = base[(size_t)b * gridDim.x + blockIdx.x];
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+  for (size_t i = lo + threadIdx.x; i < hi; i += BIN_THREADS) {
+    const float x = xyz[i * stride], y = xyz[i * stride + 1], z = xyz[i * stride + 2];
+    const int cx = cell_coord(x, x0, inv_g, W);
+    const int cy = cell_coord(y, y0, inv_g, H);
+    const int dst = atomicAdd(&cur[(cy * W + cx) >> bin_shift], 1);
+    out[dst] = make_float4(x, y, z, __int_as_float((int)i));
+  }
+}
+
+// one workgroup per bin: in[T0, T1) -> the bin's cells of cell_start, out[T0, T1) grouped by cell (arrival order)
+__global__ __launch_bounds__(BIN_CELL_THREADS) void k_bin_cells(const float4 *in, int n, float x0, float y0,
+                                                                float inv_g, int W, int H, int bin_shift,
+                                                                int nbins, int nwg, const int *base, int ncell,
+                                                                int *cell_start, float4 *out) {
+  __shared__ int cnt[BIN_CELLS_MAX];
+  __shared__ int wave_tot[BIN_CELL_THREADS / WAVE];
+  const int bin = blockIdx.x, tid = threadIdx.x;
+  const int bin_cells = 1 << bin_shift;
+  const int c0 = bin << bin_shift;
+  const int T0 = base[(size_t)bin * nwg];
+  const int T1 = (bin + 1 < nbins) ? base[(size_t)(bin + 1) * nwg] : n;
+  for (int k = tid; k < bin_cells; k += BIN_CELL_THREADS) cnt[k] = 0;
+  __syncthreads();
+  for (int i = T0 + tid; i < T1; i += BIN_CELL_THREADS) {
+    const float4 r = in[i];
+    const int c = cell_coord(r.y, y0, inv_g, H) * W + cell_coord(r.x, x0, inv_g, W);
+    atomicAdd(&cnt[c - c0], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the counters in place: a run of consecutive counters per thread, waves, workgroup
+  const int per = bin_cells / BIN_CELL_THREADS > 0 ? bin_cells / BIN_CELL_THREADS : 1;  // (bin_cells >= 1024)
+  const int k0 = tid * per;
+  int local = 0;
+  if (k0 < bin_cells)
+    for (int k = 0; k < per; ++k) local += cnt[k0 + k];
+  int inc = local;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const int up = __shfl_up(inc, d);
+    if (lane_id() >= d) inc += up;
+  }
+  const int w = tid >> 6;
+  if (lane_id() == WAVE - 1) wave_tot[w] = inc;
+  __syncthreads();
+  int run = inc - local;
+  for (int k = 0; k < w; ++k) run += wave_tot[k];
+  if (k0 < bin_cells)
+    for (int k = 0; k < per; ++k) {
+      const int v = cnt[k0 + k];
+      cnt[k0 + k] = run;
+      if (c0 + k0 + k < ncell) cell_start[c0 + k0 + k] = T0 + run;
+      run += v;
+    }
+  if (bin == nbins - 1 && tid == 0) cell_start[ncell] = n;
+  __syncthreads();
+  for (int i = T0 + tid; i < T1; i += BIN_CELL_THREADS) {
+    const float4 r = in[i];
+    const int c = cell_coord(r.y, y0, inv_g, H) * W + cell_coord(r.x, x0, inv_g, W);
+    out[T0 + atomicAdd(&cnt[c - c0], 1)] = r;
+  }
+}
+
 // The atomic rank above is arrival order; sorting every cell by original index makes the index
 // (and therefore every fp64 accumulation order downstream) independent of scheduling.
 constexpr int CSORT_CAP = 3072;  // points of 256 consecutive cells staged in LDS (48 KB)
@@ -2154,6 +2257,32 @@ void launch_scatter_sort_aos(const float *d_xyz, size_t n, size_t stride, const 
                      d_cell_of, d_rank, d_cell_start, (float4 *)d_aos);
   hipLaunchKernelGGL(k_cell_sort_aos, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d_cell_start,
                      (const float4 *)d_aos, x, y, z, perm, pt);
+}
+
+bool index_bins_plan(size_t n, size_t ncell, int *bin_shift, int *nbins, int *nwg) {
+  int shift = 10;
+  while (((ncell >> shift) + 1) > (size_t)BIN_MAX) ++shift;
+  if ((1 << shift) > BIN_CELLS_MAX || n >= 0x7FFFFFF0u) return false;
+  *bin_shift = shift;
+  *nbins = (int)((ncell + ((size_t)1 << shift) - 1) >> shift);
+  *nwg = (int)std::min<size_t>(BIN_WG, std::max<size_t>(1, (n + 8191) / 8192));
+  return true;
+}
+void launch_index_bins(const float *d_xyz, size_t n, size_t stride, float x0, float y0, float inv_g, int W, int H,
+                       int ncell, int bin_shift, int nbins, int nwg, int *d_hist, int *d_base, int *d_tmp,
+                       float4 *d_scratch_a, float4 *d_scratch_b, int *d_cell_start, float *x, float *y, float *z,
+                       int *perm, float4 *pt, hipStream_t s) {
+  const size_t chunk = (n + nwg - 1) / nwg;
+  hipLaunchKernelGGL(k_bin_count, dim3(nwg), dim3(BIN_THREADS), 0, s, d_xyz, n, stride, x0, y0, inv_g, W, H,
+                     bin_shift, nbins, chunk, d_hist);
+  launch_exclusive_scan(d_hist, d_base, nbins * nwg, d_tmp, s);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(nwg), dim3(BIN_THREADS), 0, s, d_xyz, n, stride, x0, y0, inv_g, W, H,
+                     bin_shift, nbins, chunk, (const int *)d_base, d_scratch_a);
+  hipLaunchKernelGGL(k_bin_cells, dim3(nbins), dim3(BIN_CELL_THREADS), 0, s, (const float4 *)d_scratch_a, (int)n,
+                     x0, y0, inv_g, W, H, bin_shift, nbins, nwg, (const int *)d_base, ncell, d_cell_start,
+                     d_scratch_b);
+  hipLaunchKernelGGL(k_cell_sort_aos, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, (const int *)d_cell_start,
+                     (const float4 *)d_scratch_b, x, y, z, perm, pt);
 }
 
 void launch_probe_collision(const MapView &m, QueryParams p, float threshold, const float *d_xy,
