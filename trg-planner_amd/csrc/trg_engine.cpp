@@ -86,6 +86,12 @@ struct DevMap {
   int top_m = 0;
   std::vector<float> top_xy;
   std::vector<int> top_left, top_right;
+  // For the global map the top is prepared beside the build (start_map_top): its points are fetched on the aux
+  // stream and a helper thread inserts them; whoever needs the top (or replaces / frees the map) joins it first.
+  std::thread top_thread;
+  void top_wait() {
+    if (top_thread.joinable()) top_thread.join();
+  }
 };
 
 template <typename T>
@@ -390,6 +396,8 @@ struct TrgEngine {
   hipStream_t s_aux = nullptr;  // rare-event work (nearest-point tie walks) beside whatever the main stream holds
   DevMap gmap, lmap;
   IndexScratch idx_scratch;
+  float *top_xy_d = nullptr, *top_xy_h = nullptr;  // staging of start_map_top (device / pinned host)
+  hipEvent_t top_ev = nullptr;
   DeviceCounters *d_ctr = nullptr;
   unsigned *d_bounds = nullptr;
 
@@ -558,6 +566,7 @@ void free_map(DevMap &m) {
   if (m.perm) (void)hipFree(m.perm);
   if (m.pt) (void)hipFree(m.pt);
   if (m.cell_start) (void)hipFree(m.cell_start);
+  m.top_wait();
   m = DevMap();
 }
 
@@ -569,7 +578,10 @@ inline float key_to_float(unsigned k) {
 }
 
 // ---- map index build ---------------------------------------------------------------------------
+void start_map_top(TrgEngine *e, DevMap &m);
+
 TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_t stride) {
+  m.top_wait();  // (a helper of the previous build still reads the arrays that are replaced below)
   auto t_host = Clock::now();
   m.valid = false;
   if (n == 0) {
@@ -706,13 +718,15 @@ TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_
   m.view.H = H;
   m.view.n = (int)n;
   m.valid = true;
-  m.top_m = 0;  // (the top of the insertion tree is rebuilt on demand)
+  m.top_wait();
+  m.top_m = 0;  // (the top of the insertion tree: on demand, for the global map beside the build)
   if (&m == &e->gmap) {
     e->stats.map_points = n;
     e->stats.ms_index_build = ms;
     // read xyz once, write the cell-sorted SoA once, cell ids once
     e->stats.bytes_index_build = (uint64_t)(12 + 12 + 4) * n;
     e->stats.ms_set_map_total = ms_since(t_host);
+    start_map_top(e, m);
   }
   return TRG_OK;
 }
@@ -952,17 +966,7 @@ constexpr int MAP_TOP_POINTS = 8192;  // points of the host-side top of the map 
 
 // The first MAP_TOP_POINTS points of the cloud, inserted like kd_insert does (kdtree.c:179-198: `<` goes
 // left, the axis alternates with the depth): the top of the reference's map tree, node k = cloud point k.
-TrgStatus ensure_map_top(TrgEngine *e, DevMap &m) {
-  if (m.top_m > 0) return TRG_OK;
-  const int M = (int)std::min<size_t>(m.n, MAP_TOP_POINTS);
-  float *d_xy = nullptr;
-  HIPCHK(e, hipMalloc((void **)&d_xy, (size_t)M * 2 * sizeof(float)));
-  launch_collect_first(m.view, M, d_xy, e->s_aux);
-  m.top_xy.resize((size_t)M * 2);
-  hipError_t he = hipMemcpyAsync(m.top_xy.data(), d_xy, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToHost, e->s_aux);
-  if (he == hipSuccess) he = hipStreamSynchronize(e->s_aux);
-  (void)hipFree(d_xy);
-  if (he != hipSuccess) return e->fail(TRG_ERR_DEVICE, std::string("map top: ") + hipGetErrorString(he));
+static void insert_map_top(DevMap &m, int M) {
   m.top_left.assign(M, -1);
   m.top_right.assign(M, -1);
   for (int k = 1; k < M; ++k) {
@@ -980,7 +984,54 @@ TrgStatus ensure_map_top(TrgEngine *e, DevMap &m) {
     }
   }
   m.top_m = M;
+}
+
+TrgStatus ensure_map_top(TrgEngine *e, DevMap &m) {
+  m.top_wait();  // (the global map's top is prepared beside the build)
+  if (m.top_m > 0) return TRG_OK;
+  const int M = (int)std::min<size_t>(m.n, MAP_TOP_POINTS);
+  float *d_xy = nullptr;
+  HIPCHK(e, hipMalloc((void **)&d_xy, (size_t)M * 2 * sizeof(float)));
+  launch_collect_first(m.view, M, d_xy, e->s_aux);
+  m.top_xy.resize((size_t)M * 2);
+  hipError_t he = hipMemcpyAsync(m.top_xy.data(), d_xy, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToHost, e->s_aux);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->s_aux);
+  (void)hipFree(d_xy);
+  if (he != hipSuccess) return e->fail(TRG_ERR_DEVICE, std::string("map top: ") + hipGetErrorString(he));
+  insert_map_top(m, M);
   return TRG_OK;
+}
+
+// The same beside the build: the tie-breaking scratch is allocated, the first points are fetched on the aux
+// stream, and a helper thread waits for them and inserts them while the graph is being built -- the first
+// nearest-point tie of a build otherwise paid ~0.9 ms for all of this inside the level loop.  Failures are
+// silent here: ensure_map_top then does the work on demand.
+void start_map_top(TrgEngine *e, DevMap &m) {
+  m.top_wait();
+  m.top_m = 0;
+  if (m.n == 0) return;
+  if (ensure_tie_scratch(e) != TRG_OK) return;
+  const int M = (int)std::min<size_t>(m.n, MAP_TOP_POINTS);
+  if (!e->top_xy_d && hipMalloc((void **)&e->top_xy_d, (size_t)MAP_TOP_POINTS * 2 * sizeof(float)) != hipSuccess) return;
+  if (!e->top_xy_h &&
+      hipHostMalloc((void **)&e->top_xy_h, (size_t)MAP_TOP_POINTS * 2 * sizeof(float), hipHostMallocDefault) != hipSuccess)
+    return;
+  if (!e->top_ev && hipEventCreateWithFlags(&e->top_ev, hipEventDisableTiming) != hipSuccess) return;
+  launch_collect_first(m.view, M, e->top_xy_d, e->s_aux);
+  if (hipMemcpyAsync(e->top_xy_h, e->top_xy_d, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToHost, e->s_aux) !=
+          hipSuccess ||
+      hipEventRecord(e->top_ev, e->s_aux) != hipSuccess)
+    return;
+  const int dev = e->device;
+  hipEvent_t ev = e->top_ev;
+  const float *src = e->top_xy_h;
+  DevMap *mp = &m;
+  m.top_thread = std::thread([dev, ev, src, mp, M] {
+    (void)hipSetDevice(dev);
+    if (hipEventSynchronize(ev) != hipSuccess) return;
+    mp->top_xy.assign(src, src + (size_t)M * 2);
+    insert_map_top(*mp, M);
+  });
 }
 
 TrgStatus map_first_of_two(TrgEngine *e, DevMap &m, float qx, float qy, const TiePoint &A,
@@ -2048,6 +2099,9 @@ void trg_engine_destroy(TrgEngine *e) {
     if (e->d_sin) (void)hipFree(e->d_sin);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->d_bounds) (void)hipFree(e->d_bounds);
+    if (e->top_xy_d) (void)hipFree(e->top_xy_d);
+    if (e->top_xy_h) (void)hipHostFree(e->top_xy_h);
+    if (e->top_ev) (void)hipEventDestroy(e->top_ev);
     for (void *p : {(void *)e->idx_scratch.cell_of, (void *)e->idx_scratch.rank, (void *)e->idx_scratch.counts,
                     (void *)e->idx_scratch.tmp, e->idx_scratch.aos, (void *)e->idx_scratch.hist,
                     (void *)e->idx_scratch.base, (void *)e->idx_scratch.bin_tmp})
