@@ -933,16 +933,9 @@ __device__ __forceinline__ void sweep_discs(const WaveTile &tile, int T, const f
 // One wave: the position-only part of TRG::wireEdge up to the moments of the covariance
 // (trg.cpp:269-338).  Writes the nine moments of an accepted edge into rec; the caller stores the
 // record header from the returned fields.
-// Hook: mid() is called once between the tile's loads and the sweeps over it -- a caller with an unrelated
-// chain of dependent global accesses of its own (k_level_spec: the candidate's hash entry) advances it there,
-// so that its round trips pass behind this function's work instead of after it.
-struct NoEdgeHook {
-  __device__ __forceinline__ void mid() {}
-};
-template <class Hook>
-__device__ EdgeMidOut edge_gather_h(const MapView &m, const QueryParams &p, float x1, float y1,
-                                    float z1, float x2, float y2, float z2, WaveTile &tile,
-                                    float *rec, DeviceCounters *ctr, Hook &hook) {
+__device__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float x1, float y1,
+                                  float z1, float x2, float y2, float z2, WaveTile &tile,
+                                  float *rec, DeviceCounters *ctr) {
   const int lane = lane_id();
   EdgeMidOut o;
   o.n_pts = 0;
@@ -1001,7 +994,6 @@ __device__ EdgeMidOut edge_gather_h(const MapView &m, const QueryParams &p, floa
   EDGE_CUT(1)  // geometry only
   int staged_in_range = 0;
   const int T = stage_tile(m, box, tile, cf, staged_in_range);
-  hook.mid();
   if (TRG_EDGE_STAGE_CUT == 2) {  // + tile staging (keep its results alive)
     o.status = EDGE_SEG + (T + staged_in_range > 1000000) +
                (tile.z[lane] + tile.xy[lane].x + tile.xy[lane + 64].y == 12345.0f);
@@ -1203,13 +1195,6 @@ __device__ EdgeMidOut edge_gather_h(const MapView &m, const QueryParams &p, floa
   reduce_store_moments(tile, mo, rec);
   o.status = EDGE_OK | g.uncertain;
   return o;
-}
-
-__device__ __forceinline__ EdgeMidOut edge_gather(const MapView &m, const QueryParams &p, float x1, float y1,
-                                                  float z1, float x2, float y2, float z2, WaveTile &tile,
-                                                  float *rec, DeviceCounters *ctr) {
-  NoEdgeHook h;
-  return edge_gather_h(m, p, x1, y1, z1, x2, y2, z2, tile, rec, ctr, h);
 }
 
 // lane 0 writes the 16-byte header of a mid record (edge_gather wrote the moments)
