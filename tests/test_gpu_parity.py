@@ -52,6 +52,27 @@ def test_map_index_is_sorted_permutation(mountain_small):
     assert np.all(np.diff(perm)[same] > 0)  # deterministic order inside a cell
 
 
+def test_map_index_through_bins_equals_the_direct_build(mountain_small, monkeypatch):
+    """The index built through bins (the default) and the one built with global atomics (huge grids only,
+    forced here through TRG_INDEX_DIRECT) are the same arrays: the order inside a cell is by original index
+    in both.  A shuffled cloud (as the benchmark's) and one in scan order."""
+    rng = np.random.default_rng(5)
+    for cloud in (mountain_small[rng.permutation(mountain_small.shape[0])], np.ascontiguousarray(mountain_small)):
+        n = cloud.shape[0]
+        monkeypatch.delenv("TRG_INDEX_DIRECT", raising=False)
+        e1 = _engine({})
+        e1.set_global_map(cloud)
+        a = e1.map_index("global", n)
+        monkeypatch.setenv("TRG_INDEX_DIRECT", "1")
+        e2 = _engine({})
+        e2.set_global_map(cloud)
+        b = e2.map_index("global", n)
+        monkeypatch.delenv("TRG_INDEX_DIRECT", raising=False)
+        for u, v in zip(a[:4], b[:4]):
+            assert np.array_equal(u, v)
+        assert tuple(a[4]) == tuple(b[4]) and tuple(a[5]) == tuple(b[5])
+
+
 def test_sampler_table_matches_oracle(oa):
     e = _engine({})
     o = oa.Oracle()
