@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
 """Randomised parity soak (GPU box): engine vs CPU oracle over random terrains, sample counts, sampler
-seeds / direction counts and starts; prints one line per case and a summary."""
+seeds / direction counts and starts; prints one line per case and a summary.
+
+A case whose graphs are bit-equal in structure but where some weight differs by more than 1e-5 from the
+oracle's literal fp32 restatement of trg.cpp:332-338 is looked at a second time: the same build by the oracle
+with the covariance accumulated in fp64 (its second witness, `set_cov_f64`).  If the engine agrees with that
+witness to 2e-6 on every edge, the difference is the fp32 restatement's own summation noise on a
+near-degenerate covariance (the reference's Eigen build sums in yet another, unknowable order) and the case
+is reported as `fp32-noise`, with both distances; anything else is a MISMATCH."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "trg-planner_amd"))
@@ -15,6 +22,8 @@ from conftest import assert_graph_equal
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+noise = 0
+wit_max, wit_diff_entries, wit_entries = 0.0, 0, 0
 t_all = time.time()
 for case in range(n_cases):
     nx, ny = int(rng.integers(150, 420)), int(rng.integers(150, 420))
@@ -55,11 +64,47 @@ for case in range(n_cases):
         assert st["trials"] == c["trials"] and st["samples"] == c["samples"], (st["trials"], c["trials"])
         res = "ok"
     except AssertionError as ex:
-        bad += 1
-        res = "MISMATCH " + str(ex)[:200]
+        res = None
+        try:  # structure equal and only weights off?  ask the fp64 witness
+            from conftest import weight_report
+            ge, go = e.graph("global"), o.graph(0)
+            if ge.V == go.V and ge.E == go.E and np.array_equal(ge.col, go.col) and np.array_equal(ge.rowptr, go.rowptr):
+                o2 = oa.Oracle(**prm)
+                o2.set_sampler(sseed, 0, bits)
+                o2.set_cov_f64(True)
+                o2.set_global_map(cloud)
+                o2.init_graph(start)
+                g2 = o2.graph(0)
+                if np.array_equal(g2.col, ge.col):
+                    f_e, n_e, mx_e = weight_report(ge.w, g2.w, 2e-6)
+                    f_o, n_o, mx_o = weight_report(go.w, g2.w, 1e-5)
+                    f_x, n_x, mx_x = weight_report(ge.w, go.w, 1e-5)
+                    if n_e == 0 and f_e == 0:
+                        noise += 1
+                        res = (f"fp32-noise: {n_x} entries over 1e-5 vs the fp32 restatement (max {mx_x:.2e}); engine vs fp64 "
+                               f"witness max {mx_e:.2e}; fp32 restatement vs fp64 witness {n_o} over 1e-5 (max {mx_o:.2e})")
+                o2.close()
+        except Exception as ex2:  # noqa: BLE001
+            res = None
+        if res is None:
+            bad += 1
+            res = "MISMATCH " + str(ex)[:200]
+    if res == "ok":  # the fp64 witness for every case: how far is the engine from it?
+        o2 = oa.Oracle(**prm)
+        o2.set_sampler(sseed, 0, bits)
+        o2.set_cov_f64(True)
+        o2.set_global_map(cloud)
+        o2.init_graph(start)
+        dw = np.abs(e.graph("global").w.astype(np.float64) - o2.graph(0).w.astype(np.float64))
+        wit_max = max(wit_max, float(dw.max()) if dw.size else 0.0)
+        wit_diff_entries += int((dw != 0).sum())
+        wit_entries += int(dw.size)
+        o2.close()
     g = e.graph("global")
     print(line + f"V={g.V} E={g.E} dev={st['used_device_bfs']} fallbacks={st['bfs_fallbacks']} host_levels={st['bfs_host_levels']} "
           f"tie_fixups={st['bfs_tie_fixups']} nn_ties={st['nn_ties']} map_ties={st['map_nn_resolved']} {res}", flush=True)
     e.close()
     o.close()
-print(f"{n_cases} cases, {bad} mismatches, {time.time() - t_all:.1f} s")
+print(f"{n_cases} cases, {bad} mismatches, {noise} with fp32 summation noise above 1e-5 (engine = fp64 witness), {time.time() - t_all:.1f} s")
+print(f"engine vs the oracle's fp64-covariance witness over the {n_cases - bad - noise} plain cases: {wit_diff_entries} of {wit_entries} "
+      f"directed entries differ at all, max |dw| {wit_max:.2e}")

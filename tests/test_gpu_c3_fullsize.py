@@ -5,7 +5,10 @@ scripts/fullscale_parity.py on a GPU box: the oracle needs ~2.5 minutes of host 
 Bit-exact: V', E', rowptr, col, state, node xyz, edge dist, creation ids (sha256 of the arrays).
 Weights: a fixed random sample of 65 536 edges against the oracle's values, every one within 1e-5
 (clamp flips counted apart and bounded by what the digest run saw); zero-weight edge count and the
-weight sum of the whole graph against the oracle's."""
+weight sum of the whole graph against the oracle's.
+And against the oracle's SECOND witness (the same restatement with the covariance accumulated in fp64, as the
+engine does; tests/golden/c3_witness_digest.json from scripts/fullscale_witness_c3.py): ALL 6 719 294 weights
+are the same floats -- one SHA-256 over the weight array."""
 import hashlib
 import json
 import os
@@ -63,4 +66,8 @@ def test_c3_fullsize_against_oracle_digest(synth):
     wsum = float(g.w.astype(np.float64).sum())
     # every edge within 1e-5 would allow E * 1e-5; the digest run measured 2e-6 at worst
     assert abs(wsum - dg["w_sum"]) <= g.E * 3e-6 + 0.2 * max(known_flips, 1), (wsum, dg["w_sum"])
+    # the fp64-covariance witness of the oracle: every weight bit for bit
+    wd = json.load(open(os.path.join(GOLD, "c3_witness_digest.json")))
+    assert (g.V, g.E) == (wd["V"], wd["E"])
+    assert _sha(g.w, np.float32) == wd["w_sha256_fp64_witness"]
     _invariants(g, prm["expand_dist"])
