@@ -205,6 +205,15 @@ def test_init_graph_parity(oa, request, case, replay):
     assert_graph_equal(pre_e, pre_o, WEIGHT_TOL)
     ge, go = e.graph("global"), o.graph(0)
     assert_graph_equal(ge, go, WEIGHT_TOL)
+    # the oracle's second witness (covariance accumulated in fp64, as the engine does): the same floats
+    o2 = oa.Oracle(**prm)
+    o2.set_sampler(7, 0, 16)
+    o2.set_cov_f64(True)
+    o2.set_global_map(cloud)
+    assert o2.init_graph(start)
+    g2 = o2.graph(0)
+    assert np.array_equal(g2.col, ge.col)
+    assert np.array_equal(ge.w.view(np.uint32), g2.w.view(np.uint32)), float(np.abs(ge.w - g2.w).max())
     st = e.stats()
     c = o.counters()
     assert st["expanded_nodes"] == c["expanded"]
