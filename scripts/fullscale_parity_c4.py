@@ -27,7 +27,9 @@ import tiled_oracle  # noqa: E402
 import trg_planner  # noqa: E402
 from trg_planner import synth, tiled  # noqa: E402
 
-a = [int(x) for x in sys.argv[1:5]] if len(sys.argv) >= 5 else [3200, 3125, 2, 2]
+F64 = "f64" in sys.argv  # the oracle's second witness (covariance accumulated in fp64): weights compared bit for bit
+argv = [x for x in sys.argv[1:] if x != "f64"]
+a = [int(x) for x in argv[:4]] if len(argv) >= 4 else [3200, 3125, 2, 2]
 nx, ny, cols, rows = a
 HALO, SEED, SSEED = 11, 20250418, 7
 prm = dict(oa.MOUNTAIN, sample_num=16)
@@ -60,6 +62,7 @@ for t in range(ntiles):
     cloud = synth.mountain_tile(*wins[t], seed=SEED)
     o = oa.Oracle(**prm)
     o.set_sampler(SSEED, 0, 16)
+    o.set_cov_f64(F64)
     o.set_tile(cores[t], epoch=t)
     o.set_global_map(cloud)
     c = cores[t]
@@ -89,6 +92,18 @@ res = {"nx": nx, "ny": ny, "layout": [cols, rows], "points_total": int(nx * ny),
        "weight_max_abs_diff_excl_flips": float(dw[~flip].max()) if same and dw.size else None,
        "weight_over_1e-5_excl_flips": int((dw[~flip] > 1e-5).sum()) if same else None,
        "clamp_flips": int(flip.sum()) if same else None}
+if F64:
+    res["witness"] = "fp64 covariance (set_cov_f64)"
+    res["entries_that_differ_at_all"] = int((dw != 0).sum()) if same else None
+    res["witness_w_sha256"] = sha(OG["w"], np.float32)
+    res["engine_w_sha256"] = sha(G["w"], np.float32)
+    print(json.dumps(res, indent=1))
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "fullscale_witness_c4.json"), "w"), indent=1)
+    if same:
+        json.dump({"V": int(OG["V"]), "E": int(OG["col"].size), "w_sha256_fp64_witness": res["witness_w_sha256"],
+                   "made_by": "scripts/fullscale_parity_c4.py f64 (the TILED ORACLE's graph with set_cov_f64)"},
+                  open(os.path.join(ROOT, "gpurun_out", "c4_witness_digest.json"), "w"), indent=1)
+    sys.exit(0)
 print(json.dumps(res, indent=1))
 out = os.path.join(ROOT, "gpurun_out", "golden")
 os.makedirs(out, exist_ok=True)

@@ -63,6 +63,11 @@ def test_c4_fullsize_tiled_against_tiled_oracle_digest(synth):
     assert abs(zero - dg["w_zero_edges"]) <= 2 * max(known, 1), (zero, dg["w_zero_edges"])
     wsum = float(G["w"].astype(np.float64).sum())
     assert abs(wsum - dg["w_sum"]) <= dg["E"] * 3e-6 + 0.2 * max(known, 1), (wsum, dg["w_sum"])
+    # the tiled oracle's second witness (covariance accumulated in fp64, scripts/fullscale_parity_c4.py f64): every
+    # weight of the assembled graph, the 5 431 stitched cross edges included, bit for bit
+    wd = json.load(open(os.path.join(GOLD, "c4_witness_digest.json")))
+    assert (G["V"], int(G["col"].size)) == (wd["V"], wd["E"])
+    assert _sha(G["w"], np.float32) == wd["w_sha256_fp64_witness"]
     # the seam connects the tiles: every tile has edges into another one
     src = np.repeat(np.arange(G["V"]), np.diff(G["rowptr"]))
     tile_of = np.searchsorted(G["offsets"], np.arange(G["V"]), side="right") - 1
