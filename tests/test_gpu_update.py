@@ -33,12 +33,20 @@ def test_update_graph_parity(oa, mountain_gentle, replay):
     o.set_global_map(mountain_gentle)
     assert o.init_graph([15.0, 15.0, 0.0])
     assert_graph_equal(e.graph("global"), o.graph(0), TOL)
+    # the oracle's second witness (covariance accumulated in fp64, as the engine does) goes through the same
+    # updates: its weights are the engine's, bit for bit
+    o2 = oa.Oracle(**prm)
+    o2.set_sampler(5, 0, 16)
+    o2.set_cov_f64(True)
+    o2.set_global_map(mountain_gentle)
+    assert o2.init_graph([15.0, 15.0, 0.0])
 
     poses = [(12.0, 12.0), (13.0, 12.5), (14.0, 13.0)]
     for k, pose in enumerate(poses):
         obs = _obs_crop(mountain_gentle, pose, 4.0, box=(pose[0] + 2.0, pose[1] + 1.0, 0.6))
         e.set_local_map(pose, obs)
         o.set_local_map(pose, obs)
+        o2.set_local_map(pose, obs)
         # isFrontier / isCollision on the local map agree before the update
         loc = e.graph("local")
         assert loc.V > 10
@@ -50,7 +58,11 @@ def test_update_graph_parity(oa, mountain_gentle, replay):
         assert np.array_equal(ce, co) and np.array_equal(ne, no)
         e.update_graph()
         o.update_graph()
+        o2.update_graph()
         ge, go = e.graph("global"), o.graph(0)
+        g2 = o2.graph(0)
+        assert np.array_equal(g2.col, ge.col)
+        assert np.array_equal(ge.w.view(np.uint32), g2.w.view(np.uint32)), (k, float(np.abs(ge.w - g2.w).max()))
         assert ge.V == go.V and ge.E == go.E, (k, ge.V, go.V, ge.E, go.E)
         assert np.array_equal(ge.rowptr, go.rowptr) and np.array_equal(ge.col, go.col)
         assert np.array_equal(ge.state, go.state)
