@@ -30,7 +30,13 @@
  * algorithm (Eigen/src/SVD/JacobiSVD.h, Eigen/src/Jacobi/Jacobi.h) in fp32 with
  * plain left-to-right summation; Eigen's own packet summation order for
  * mean/covariance is unknowable here, so weights carry summation-order noise of
- * a few fp32 ulps relative to a real Eigen build.
+ * a few fp32 ulps relative to a real Eigen build.  A second witness
+ * (trg_oracle_set_cov_f64) accumulates the same mean / centred rows / covariance
+ * in fp64 and rounds once: the HIP engine, which accumulates in fp64 as well,
+ * reproduces that witness's weights bit for bit (tests/test_gpu_weight_witness.py,
+ * the C3 / C4 full-size digests), while THIS fp32 restatement sits 1-2e-5 away
+ * from it on about one near-degenerate edge per million -- the size of the noise
+ * any fp32 summation order, Eigen's included, puts on such an edge.
  *
  * Deliberate, documented deviation: the reference seeds std::mt19937 from
  * std::random_device (trg.cpp:20), so it has no canonical sample stream.  The
