@@ -421,9 +421,15 @@ def main():
                 if tj.get("kernel_source_sha256") != sha:
                     traffic_note = (f"{os.path.relpath(tpath, ROOT)} was measured on other kernel sources "
                                     f"(sha256 {str(tj.get('kernel_source_sha256'))[:12]} != {sha[:12]}): not quoted")
-                elif all(k in tj for k in parts):
-                    traffic = sum(tj[k]["hbm_bytes_per_dispatch"] for k in parts)
-                    traffic_src = os.path.relpath(tpath, ROOT)
+                else:
+                    def per_launch(k):  # a kernel's variants (k, k<4>, k<8>, ...): one of them runs per level
+                        v = [tj[n] for n in tj if isinstance(tj[n], dict) and (n == k or n.startswith(k + "<"))]
+                        nd = sum(x["dispatches"] for x in v)
+                        return sum(x["hbm_bytes_per_dispatch"] * x["dispatches"] for x in v) / nd if nd else None
+                    per = [per_launch(k) for k in parts]
+                    if all(x is not None for x in per):
+                        traffic = sum(per)
+                        traffic_src = os.path.relpath(tpath, ROOT)
                 break
         out = {
             "metric": "TRG nodes+edges built/sec", "value": items / dt, "unit": "nodes+edges/s",
