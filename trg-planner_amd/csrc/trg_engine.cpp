@@ -577,251 +577,7 @@ inline float key_to_float(unsigned k) {
   return f;
 }
 
-// ---- map index build ---------------------------------------------------------------------------
-void start_map_top(TrgEngine *e, DevMap &m);
-
-TrgStatus build_map(TrgEngine *e, DevMap &m, const float *d_xyz, size_t n, size_t stride) {
-  m.top_wait();  // (a helper of the previous build still reads the arrays that are replaced below)
-  auto t_host = Clock::now();
-  m.valid = false;
-  if (n == 0) {
-    m.n = 0;
-    return TRG_OK;
-  }
-  if (n > (size_t)0x7FFFFFF0) return e->fail(TRG_ERR_CAPACITY, "more than 2^31 map points");
-  hipStream_t s = e->s_main;
-  hipEvent_t ev0, ev1;
-  HIPCHK(e, hipEventCreate(&ev0));
-  HIPCHK(e, hipEventCreate(&ev1));
-  HIPCHK(e, hipEventRecord(ev0, s));
-  launch_init_bounds(e->d_bounds, s);
-  launch_bounds(d_xyz, n, stride, e->d_bounds, s);
-  unsigned hb[4];
-  HIPCHK(e, hipMemcpyAsync(hb, e->d_bounds, sizeof(hb), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipStreamSynchronize(s));
-  const float x0 = key_to_float(hb[0]), y0 = key_to_float(hb[1]);
-  const float x1 = key_to_float(hb[2]), y1 = key_to_float(hb[3]);
-  if (!(x1 >= x0) || !(y1 >= y0) || !std::isfinite(x0) || !std::isfinite(x1) ||
-      !std::isfinite(y0) || !std::isfinite(y1)) {
-    return e->fail(TRG_ERR_INVALID_ARG, "map has non-finite coordinates");
-  }
-  // cell size = robot_size: a collision disc touches a 3x3 block, an edge ellipse <= 7x7
-  float g = e->prm.robot_size;
-  if (!(g > 0)) g = 0.3f;
-  const double max_cells = 64.0 * 1024 * 1024;
-  while (((double)(x1 - x0) / g + 2) * ((double)(y1 - y0) / g + 2) > max_cells) g *= 2.0f;
-  const float inv_g = 1.0f / g;
-  const int W = (int)floorf((x1 - x0) * inv_g) + 1;
-  const int H = (int)floorf((y1 - y0) * inv_g) + 1;
-  const size_t ncell = (size_t)W * H;
-
-  if (m.cap_pts < n) {
-    if (m.x) (void)hipFree(m.x);
-    if (m.y) (void)hipFree(m.y);
-    if (m.z) (void)hipFree(m.z);
-    if (m.perm) (void)hipFree(m.perm);
-    if (m.pt) (void)hipFree(m.pt);
-    m.x = m.y = m.z = nullptr;
-    m.perm = nullptr;
-    m.pt = nullptr;
-    HIPCHK(e, hipMalloc((void **)&m.pt, n * sizeof(float4)));
-    HIPCHK(e, hipMalloc((void **)&m.x, n * sizeof(float)));
-    HIPCHK(e, hipMalloc((void **)&m.y, n * sizeof(float)));
-    HIPCHK(e, hipMalloc((void **)&m.z, n * sizeof(float)));
-    HIPCHK(e, hipMalloc((void **)&m.perm, n * sizeof(int)));
-    m.cap_pts = n;
-  }
-  if (m.cap_cells < ncell + 1) {
-    if (m.cell_start) (void)hipFree(m.cell_start);
-    m.cell_start = nullptr;
-    HIPCHK(e, hipMalloc((void **)&m.cell_start, (ncell + 1) * sizeof(int)));
-    m.cap_cells = ncell + 1;
-  }
-  // scratch of the build, kept with the engine (allocating and freeing 240 MB per build costs as much as
-  // a kernel of it)
-  IndexScratch &sc = e->idx_scratch;
-  if (sc.cap_pts < n) {
-    if (sc.aos) (void)hipFree(sc.aos);
-    sc.aos = nullptr;
-    sc.cap_pts = 0;
-    HIPCHK(e, hipMalloc((void **)&sc.aos, n * 16));
-    sc.cap_pts = n;
-  }
-  int bin_shift = 0, nbins = 0, nwg = 0;
-  if (!getenv("TRG_INDEX_DIRECT") && index_bins_plan(n, ncell, &bin_shift, &nbins, &nwg)) {
-    // through bins of ~one cell row (trg_kernels.hip): no global atomics, no random line per point
-    const size_t nb = (size_t)nbins * nwg;
-    if (sc.cap_bins < nb) {
-      if (sc.hist) (void)hipFree(sc.hist);
-      if (sc.base) (void)hipFree(sc.base);
-      if (sc.bin_tmp) (void)hipFree(sc.bin_tmp);
-      sc.hist = sc.base = sc.bin_tmp = nullptr;
-      sc.cap_bins = 0;
-      HIPCHK(e, hipMalloc((void **)&sc.hist, (nb + 1) * sizeof(int)));
-      HIPCHK(e, hipMalloc((void **)&sc.base, (nb + 1) * sizeof(int)));
-      HIPCHK(e, hipMalloc((void **)&sc.bin_tmp, (nb / 2048 + 4) * sizeof(int)));
-      sc.cap_bins = nb;
-    }
-    // (the map's own record array is the first scratch: it is rewritten by the last kernel)
-    launch_index_bins(d_xyz, n, stride, x0, y0, inv_g, W, H, (int)ncell, bin_shift, nbins, nwg, sc.hist, sc.base,
-                      sc.bin_tmp, m.pt, (float4 *)sc.aos, m.cell_start, m.x, m.y, m.z, m.perm, m.pt, s);
-  } else {
-    if (sc.cap_direct < n) {
-      if (sc.cell_of) (void)hipFree(sc.cell_of);
-      if (sc.rank) (void)hipFree(sc.rank);
-      sc.cell_of = sc.rank = nullptr;
-      sc.cap_direct = 0;
-      HIPCHK(e, hipMalloc((void **)&sc.cell_of, n * sizeof(int)));
-      HIPCHK(e, hipMalloc((void **)&sc.rank, n * sizeof(int)));
-      sc.cap_direct = n;
-    }
-    if (sc.cap_cells < ncell) {
-      if (sc.counts) (void)hipFree(sc.counts);
-      if (sc.tmp) (void)hipFree(sc.tmp);
-      sc.counts = sc.tmp = nullptr;
-      sc.cap_cells = 0;
-      HIPCHK(e, hipMalloc((void **)&sc.counts, ncell * sizeof(int)));
-      HIPCHK(e, hipMalloc((void **)&sc.tmp, (ncell / 2048 + 4) * sizeof(int)));
-      sc.cap_cells = ncell;
-    }
-    int *d_cell_of = sc.cell_of, *d_rank = sc.rank, *d_counts = sc.counts, *d_tmp = sc.tmp;
-    HIPCHK(e, hipMemsetAsync(d_counts, 0, ncell * sizeof(int), s));
-    launch_cell_count(d_xyz, n, stride, x0, y0, inv_g, W, H, d_cell_of, d_rank, d_counts, s);
-    launch_exclusive_scan(d_counts, m.cell_start, (int)ncell, d_tmp, s);
-    launch_scatter_sort_aos(d_xyz, n, stride, d_cell_of, d_rank, (int)ncell, m.cell_start, sc.aos, m.x, m.y, m.z,
-                            m.perm, m.pt, s);
-  }
-  HIPCHK(e, hipEventRecord(ev1, s));
-  HIPCHK(e, hipStreamSynchronize(s));
-  HIPCHK(e, hipGetLastError());
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, ev0, ev1);
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-
-  m.n = n;
-  m.g = g;
-  m.bounds[0] = x0;
-  m.bounds[1] = y0;
-  m.bounds[2] = x1;
-  m.bounds[3] = y1;
-  m.view.x = m.x;
-  m.view.y = m.y;
-  m.view.z = m.z;
-  m.view.pt = m.pt;
-  m.view.perm = m.perm;
-  m.view.cell_start = m.cell_start;
-  m.view.x0 = x0;
-  m.view.y0 = y0;
-  m.view.inv_g = inv_g;
-  m.view.W = W;
-  m.view.H = H;
-  m.view.n = (int)n;
-  m.valid = true;
-  m.top_wait();
-  m.top_m = 0;  // (the top of the insertion tree: on demand, for the global map beside the build)
-  if (&m == &e->gmap) {
-    e->stats.map_points = n;
-    e->stats.ms_index_build = ms;
-    // read xyz once, write the cell-sorted SoA once, cell ids once
-    e->stats.bytes_index_build = (uint64_t)(12 + 12 + 4) * n;
-    e->stats.ms_set_map_total = ms_since(t_host);
-    start_map_top(e, m);
-  }
-  return TRG_OK;
-}
-
-// Host cloud -> HBM.  TRG::setGlobalMap / setLocalMap get a cloud in ordinary (pageable) host memory
-// (trg.cpp:179-193, 195-209); a plain hipMemcpy from there runs at a third of the link rate (the runtime
-// stages it through one pinned buffer on one thread: ~25 ms for the 120 MB of C3).  Here UP_THREADS host
-// threads copy interleaved chunks into pinned staging slots of their own and send every chunk on with
-// hipMemcpyAsync on a stream of their own, so the CPU copies and the DMA transfers overlap; a source that
-// is already pinned (hipHostMalloc / hipHostRegister / a pinned torch tensor) goes out in one async copy.
-constexpr int UP_THREADS = 4, UP_SLOTS = 2;
-constexpr size_t UP_CHUNK = (size_t)8 << 20;
-struct Uploader {
-  char *pinned = nullptr;  // UP_THREADS * UP_SLOTS chunks
-  hipStream_t st[UP_THREADS] = {};
-  hipEvent_t ev[UP_THREADS][UP_SLOTS] = {};
-  float *d_in = nullptr;   // device staging of the raw cloud (kept across calls)
-  size_t d_cap = 0;
-  void release() {
-    if (pinned) (void)hipHostFree(pinned);
-    for (auto &s : st)
-      if (s) (void)hipStreamDestroy(s);
-    for (auto &row : ev)
-      for (auto &x : row)
-        if (x) (void)hipEventDestroy(x);
-    if (d_in) (void)hipFree(d_in);
-    *this = Uploader();
-  }
-};
-
-TrgStatus staged_upload(TrgEngine *e, void *d_dst, const void *src, size_t bytes) {
-  Uploader &u = *e->uploader;
-  hipPointerAttribute_t attr;
-  const bool pinned_src = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
-  (void)hipGetLastError();  // (an ordinary malloc pointer makes the query fail: not an error)
-  if (pinned_src || bytes < UP_CHUNK) {
-    HIPCHK(e, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, e->s_main));
-    HIPCHK(e, hipStreamSynchronize(e->s_main));
-    return TRG_OK;
-  }
-  if (!u.pinned) {
-    HIPCHK(e, hipHostMalloc((void **)&u.pinned, UP_CHUNK * UP_THREADS * UP_SLOTS, hipHostMallocDefault));
-    for (int t = 0; t < UP_THREADS; ++t) {
-      HIPCHK(e, hipStreamCreateWithFlags(&u.st[t], hipStreamNonBlocking));
-      for (int k = 0; k < UP_SLOTS; ++k) HIPCHK(e, hipEventCreateWithFlags(&u.ev[t][k], hipEventDisableTiming));
-    }
-  }
-  const size_t nchunk = (bytes + UP_CHUNK - 1) / UP_CHUNK;
-  std::atomic<int> bad{0};
-  auto work = [&](int t) {
-    if (hipSetDevice(e->device) != hipSuccess) {
-      bad = 1;
-      return;
-    }
-    int use = 0;
-    for (size_t c = (size_t)t; c < nchunk; c += UP_THREADS, ++use) {
-      const int k = use % UP_SLOTS;
-      char *slot = u.pinned + ((size_t)t * UP_SLOTS + k) * UP_CHUNK;
-      if (use >= UP_SLOTS && hipEventSynchronize(u.ev[t][k]) != hipSuccess) bad = 1;  // the slot's last transfer
-      const size_t off = c * UP_CHUNK, len = std::min(UP_CHUNK, bytes - off);
-      memcpy(slot, (const char *)src + off, len);
-      if (hipMemcpyAsync((char *)d_dst + off, slot, len, hipMemcpyHostToDevice, u.st[t]) != hipSuccess) bad = 1;
-      if (hipEventRecord(u.ev[t][k], u.st[t]) != hipSuccess) bad = 1;
-    }
-    if (hipStreamSynchronize(u.st[t]) != hipSuccess) bad = 1;
-  };
-  std::vector<std::thread> thr;
-  for (int t = 1; t < UP_THREADS; ++t) thr.emplace_back(work, t);
-  work(0);
-  for (auto &th : thr) th.join();
-  if (bad) return e->fail(TRG_ERR_DEVICE, "staged upload of the cloud failed");
-  return TRG_OK;
-}
-
-TrgStatus upload_and_build(TrgEngine *e, DevMap &m, const float *xyz, size_t n, size_t stride) {
-  if (n == 0) {
-    m.n = 0;
-    m.valid = false;
-    return TRG_OK;
-  }
-  Uploader &u = *e->uploader;
-  const size_t floats = n * stride;
-  if (u.d_cap < floats) {
-    if (u.d_in) (void)hipFree(u.d_in);
-    u.d_in = nullptr;
-    u.d_cap = 0;
-    HIPCHK(e, hipMalloc((void **)&u.d_in, floats * sizeof(float)));
-    u.d_cap = floats;
-  }
-  auto t0 = Clock::now();
-  TrgStatus st = staged_upload(e, u.d_in, xyz, floats * sizeof(float));
-  e->stats.ms_upload = ms_since(t0);
-  if (st != TRG_OK) return st;
-  return build_map(e, m, u.d_in, n, stride);
-}
+#include "trg_engine_map.ipp"
 
 // ---- sampler table -----------------------------------------------------------------------------
 TrgStatus ensure_sampler(TrgEngine *e, const TrgSampler *smp) {
@@ -870,377 +626,7 @@ inline float sampler_uniform(const TrgEngine *e, uint32_t k) {
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
-// ---- synchronous probes ------------------------------------------------------------------------
-TrgStatus ensure_sync_scratch(TrgEngine *e, size_t m) {
-  if (e->sy_cap >= m) return TRG_OK;
-  size_t cap = std::max<size_t>(m, 1024);
-  HIPCHK(e, alloc_pinned(e->sy_in, cap * 3));
-  HIPCHK(e, alloc_pinned(e->sy_in2, cap * 3));
-  HIPCHK(e, alloc_pinned(e->sy_f0, cap));
-  HIPCHK(e, alloc_pinned(e->sy_f1, cap));
-  HIPCHK(e, alloc_pinned(e->sy_i0, cap));
-  HIPCHK(e, alloc_pinned(e->sy_i1, cap));
-  HIPCHK(e, alloc_pinned(e->sy_i2, cap));
-  if (e->sy_mid) (void)hipFree(e->sy_mid);
-  e->sy_mid = nullptr;
-  HIPCHK(e, hipMalloc((void **)&e->sy_mid, edge_mid_floats(cap) * sizeof(float)));
-  e->sy_cap = cap;
-  return TRG_OK;
-}
-
-DevMap *pick_map(TrgEngine *e, TrgKind k) { return k == TRG_KIND_LOCAL ? &e->lmap : &e->gmap; }
-
-// strm: the stream the probe runs in (the main stream may still hold look-ahead work of a finished replay that
-// nobody needs to wait for: the maps are read-only here)
-// radius > 0: probe discs of that radius instead of robot_size (setLocalGraph / isFrontier ask for
-// robot_size / 2, trg.cpp:214, 791) -- passed in the query parameters, the engine's own stay untouched
-TrgStatus collision_sync(TrgEngine *e, DevMap &m, float threshold, const float *xy, size_t cnt,
-                         int32_t *flag, int32_t *c_out, int32_t *n_out, hipStream_t strm = nullptr,
-                         float radius = 0.0f) {
-  if (!strm) strm = e->s_main;
-  QueryParams qp = qparams(e);
-  if (radius > 0.0f) qp.robot_size = radius;
-  if (!m.valid) {
-    // empty map: kd_nearest_range on an empty tree returns no hits -> collision (trg.cpp:749-752)
-    for (size_t i = 0; i < cnt; ++i) {
-      if (flag) flag[i] = 1;
-      if (c_out) c_out[i] = 0;
-      if (n_out) n_out[i] = 0;
-    }
-    return TRG_OK;
-  }
-  const size_t B = 1 << 20;
-  for (size_t off = 0; off < cnt; off += B) {
-    const size_t m_ = std::min(B, cnt - off);
-    TrgStatus st = ensure_sync_scratch(e, m_);
-    if (st != TRG_OK) return st;
-    memcpy(e->sy_in.h, xy + 2 * off, m_ * 2 * sizeof(float));
-    HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 2 * sizeof(float), hipMemcpyHostToDevice,
-                             strm));
-    launch_probe_collision(m.view, qp, threshold, e->sy_in.d, (int)m_, e->sy_i0.d,
-                           e->sy_i1.d, e->sy_i2.d, e->d_ctr, strm);
-    HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             strm));
-    HIPCHK(e, hipMemcpyAsync(e->sy_i1.h, e->sy_i1.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             strm));
-    HIPCHK(e, hipMemcpyAsync(e->sy_i2.h, e->sy_i2.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             strm));
-    HIPCHK(e, hipStreamSynchronize(strm));
-    HIPCHK(e, hipGetLastError());
-    if (flag) memcpy(flag + off, e->sy_i0.h, m_ * sizeof(int));
-    if (c_out) memcpy(c_out + off, e->sy_i1.h, m_ * sizeof(int));
-    if (n_out) memcpy(n_out + off, e->sy_i2.h, m_ * sizeof(int));
-  }
-  e->stats.sync_batches++;
-  return TRG_OK;
-}
-
-// ---- exact nearest-map-point tie-break ------------------------------------------------------------
-// addNode takes the z of kd_nearest's result (trg.cpp:244-247).  When several map points are at the
-// same minimal fp32 distance, kd_nearest returns the one it visits first (strict `<`, kdtree.c:343;
-// the root is the initial best, kdtree.c:393-396), which depends on the shape of the insertion-built
-// map tree.  The tree is never built here: as in kd_first_of_two (host_index.h) the visiting order
-// of two tied points is decided at their lowest common ancestor, and the common path is followed
-// by asking the GPU for "the point with the smallest original index inside this half-open region,
-// inserted after the current ancestor" -- which is exactly the root of that subtree, because
-// kd_insert appends in cloud order and sends `<` to the left (kdtree.c:179-198).
-struct TiePoint {
-  int perm;
-  float x, y;
-};
-
-TrgStatus ensure_tie_scratch(TrgEngine *e) {
-  if (e->mt_set_d) return TRG_OK;
-  HIPCHK(e, hipMalloc((void **)&e->mt_set_d, sizeof(MapTieSet)));
-  HIPCHK(e, hipMalloc((void **)&e->mt_walk_d, sizeof(MapTieWalk)));
-  HIPCHK(e, hipHostMalloc((void **)&e->mt_set_h, sizeof(MapTieSet), hipHostMallocDefault));
-  HIPCHK(e, hipHostMalloc((void **)&e->mt_walk_h, sizeof(MapTieWalk), hipHostMallocDefault));
-  return TRG_OK;
-}
-
-// which of the tied points A, B the nearest-neighbour search for q visits first: 0 = A, 1 = B.  The
-// walk (region scan + decision per tree level, ~30-50 levels on a 10 M-point map) runs on the device
-// without the host in between: the first steps (regions of millions of points) one grid-wide kernel
-// each, enqueued blindly, the rest inside a single workgroup; steps after the decision return at once.
-constexpr int MAP_TOP_POINTS = 8192;  // points of the host-side top of the map tree
-
-// The first MAP_TOP_POINTS points of the cloud, inserted like kd_insert does (kdtree.c:179-198: `<` goes
-// left, the axis alternates with the depth): the top of the reference's map tree, node k = cloud point k.
-static void insert_map_top(DevMap &m, int M) {
-  m.top_left.assign(M, -1);
-  m.top_right.assign(M, -1);
-  for (int k = 1; k < M; ++k) {
-    const float px = m.top_xy[2 * (size_t)k], py = m.top_xy[2 * (size_t)k + 1];
-    int cur = 0, axis = 0;
-    for (;;) {
-      const float split = axis ? m.top_xy[2 * (size_t)cur + 1] : m.top_xy[2 * (size_t)cur];
-      int &child = ((axis ? py : px) < split) ? m.top_left[cur] : m.top_right[cur];
-      if (child < 0) {
-        child = k;
-        break;
-      }
-      cur = child;
-      axis ^= 1;
-    }
-  }
-  m.top_m = M;
-}
-
-TrgStatus ensure_map_top(TrgEngine *e, DevMap &m) {
-  m.top_wait();  // (the global map's top is prepared beside the build)
-  if (m.top_m > 0) return TRG_OK;
-  const int M = (int)std::min<size_t>(m.n, MAP_TOP_POINTS);
-  float *d_xy = nullptr;
-  HIPCHK(e, hipMalloc((void **)&d_xy, (size_t)M * 2 * sizeof(float)));
-  launch_collect_first(m.view, M, d_xy, e->s_aux);
-  m.top_xy.resize((size_t)M * 2);
-  hipError_t he = hipMemcpyAsync(m.top_xy.data(), d_xy, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToHost, e->s_aux);
-  if (he == hipSuccess) he = hipStreamSynchronize(e->s_aux);
-  (void)hipFree(d_xy);
-  if (he != hipSuccess) return e->fail(TRG_ERR_DEVICE, std::string("map top: ") + hipGetErrorString(he));
-  insert_map_top(m, M);
-  return TRG_OK;
-}
-
-// The same beside the build: the tie-breaking scratch is allocated, the first points are fetched on the aux
-// stream, and a helper thread waits for them and inserts them while the graph is being built -- the first
-// nearest-point tie of a build otherwise paid ~0.9 ms for all of this inside the level loop.  Failures are
-// silent here: ensure_map_top then does the work on demand.
-void start_map_top(TrgEngine *e, DevMap &m) {
-  m.top_wait();
-  m.top_m = 0;
-  if (m.n == 0) return;
-  if (ensure_tie_scratch(e) != TRG_OK) return;
-  const int M = (int)std::min<size_t>(m.n, MAP_TOP_POINTS);
-  if (!e->top_xy_d && hipMalloc((void **)&e->top_xy_d, (size_t)MAP_TOP_POINTS * 2 * sizeof(float)) != hipSuccess) return;
-  if (!e->top_xy_h &&
-      hipHostMalloc((void **)&e->top_xy_h, (size_t)MAP_TOP_POINTS * 2 * sizeof(float), hipHostMallocDefault) != hipSuccess)
-    return;
-  if (!e->top_ev && hipEventCreateWithFlags(&e->top_ev, hipEventDisableTiming) != hipSuccess) return;
-  launch_collect_first(m.view, M, e->top_xy_d, e->s_aux);
-  if (hipMemcpyAsync(e->top_xy_h, e->top_xy_d, (size_t)M * 2 * sizeof(float), hipMemcpyDeviceToHost, e->s_aux) !=
-          hipSuccess ||
-      hipEventRecord(e->top_ev, e->s_aux) != hipSuccess)
-    return;
-  const int dev = e->device;
-  hipEvent_t ev = e->top_ev;
-  const float *src = e->top_xy_h;
-  DevMap *mp = &m;
-  m.top_thread = std::thread([dev, ev, src, mp, M] {
-    (void)hipSetDevice(dev);
-    if (hipEventSynchronize(ev) != hipSuccess) return;
-    mp->top_xy.assign(src, src + (size_t)M * 2);
-    insert_map_top(*mp, M);
-  });
-}
-
-TrgStatus map_first_of_two(TrgEngine *e, DevMap &m, float qx, float qy, const TiePoint &A,
-                           const TiePoint &B, int *first) {
-  hipStream_t s = e->s_aux;  // (the main stream is busy with the next level's speculative expansion)
-  TrgStatus st = ensure_map_top(e, m);
-  if (st != TRG_OK) return st;
-  MapTieWalk w{};
-  w.key = ~0ull;
-  w.lo[0] = w.lo[1] = -INFINITY;
-  w.hi[0] = w.hi[1] = INFINITY;
-  w.cur_perm = -1;
-  w.axis = 0;
-  w.qx = qx;
-  w.qy = qy;
-  w.aperm = A.perm;
-  w.bperm = B.perm;
-  w.ax = A.x;
-  w.ay = A.y;
-  w.bx = B.x;
-  w.by = B.y;
-  // the common path of A and B through the top of the tree, on the host (the same decisions as
-  // region_step on the device, trg_kernels.hip)
-  {
-    int cur = 0;
-    for (;;) {
-      const float cx = m.top_xy[2 * (size_t)cur], cy = m.top_xy[2 * (size_t)cur + 1];
-      const int axis = w.axis;
-      const float split = axis ? cy : cx;
-      const float q = axis ? qy : qx;
-      const bool near_is_left = (q - split) <= 0;
-      const float ca = axis ? A.y : A.x, cb = axis ? B.y : B.x;
-      if (cur == A.perm || cur == B.perm) {
-        const bool cur_is_a = cur == A.perm;
-        const bool other_left = (cur_is_a ? cb : ca) < split;
-        const bool other_first = other_left == near_is_left;
-        *first = cur_is_a ? (other_first ? 1 : 0) : (other_first ? 0 : 1);
-        return TRG_OK;
-      }
-      const bool a_left = ca < split, b_left = cb < split;
-      if (a_left != b_left) {
-        *first = (a_left == near_is_left) ? 0 : 1;
-        return TRG_OK;
-      }
-      if (a_left)
-        w.hi[axis] = split;
-      else
-        w.lo[axis] = split;
-      w.cur_perm = cur;
-      w.axis = axis ^ 1;
-      w.steps++;
-      const int child = a_left ? m.top_left[cur] : m.top_right[cur];
-      if (child < 0) break;  // the subtree's root is a later point: the device goes on from this region
-      cur = child;
-    }
-  }
-  *e->mt_walk_h = w;
-  HIPCHK(e, hipMemcpyAsync(e->mt_walk_d, e->mt_walk_h, sizeof(MapTieWalk), hipMemcpyHostToDevice, s));
-  for (int batch = 0; batch < 64; ++batch) {
-    // what is left of the region after the top of the tree holds ~N / 8192 points: one workgroup walks it
-    // (a full-size region -- a map smaller than the top -- cannot get here)
-    launch_map_tie_walk(m.view, e->mt_walk_d, 0, 64, s);
-    HIPCHK(e, hipMemcpyAsync(e->mt_walk_h, e->mt_walk_d, sizeof(MapTieWalk), hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipStreamSynchronize(s));
-    if (e->mt_walk_h->done == 1) {
-      *first = e->mt_walk_h->first;
-      return TRG_OK;
-    }
-    if (e->mt_walk_h->done) break;
-  }
-  return e->fail(TRG_ERR_DEVICE, "nearest-point tie-break lost its candidates (internal error)");
-}
-
-// z of the map point kd_nearest returns for (qx, qy), ties decided as the reference's tree does
-TrgStatus map_nn_exact(TrgEngine *e, DevMap &m, float qx, float qy, float *z, bool *found) {
-  TrgStatus st = ensure_tie_scratch(e);
-  if (st != TRG_OK) return st;
-  hipStream_t s = e->s_aux;  // (the map is read-only here; the main stream may hold speculative work)
-  launch_map_tied_set(m.view, qx, qy, e->prm.robot_size, e->mt_set_d, s);
-  HIPCHK(e, hipMemcpyAsync(e->mt_set_h, e->mt_set_d, sizeof(MapTieSet), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipStreamSynchronize(s));
-  const MapTieSet T = *e->mt_set_h;
-  *found = T.count > 0;
-  if (!*found) return TRG_OK;
-  const int n = std::min(T.count, MAPTIE_SET_CAP);
-  // lowest original index first, so that an unresolved case equals the hot kernels' provisional pick
-  int order[MAPTIE_SET_CAP];
-  for (int i = 0; i < n; ++i) order[i] = i;
-  std::sort(order, order + n, [&](int a, int b) { return T.perm[a] < T.perm[b]; });
-  *z = T.z[order[0]];
-  if (T.count == 1) return TRG_OK;
-  if (T.count > MAPTIE_SET_CAP) {
-    e->stats.map_nn_unresolved++;
-    return TRG_OK;
-  }
-  e->stats.map_nn_resolved++;
-  bool same_z = true;
-  for (int i = 1; i < n; ++i) same_z = same_z && T.z[order[i]] == T.z[order[0]];
-  if (same_z) return TRG_OK;
-  if (T.perm[order[0]] == 0) return TRG_OK;  // the root keeps an equal distance (kdtree.c:393-396)
-  int w = order[0];
-  for (int i = 1; i < n; ++i) {
-    const int c = order[i];
-    const TiePoint A{T.perm[w], T.x[w], T.y[w]}, B{T.perm[c], T.x[c], T.y[c]};
-    int first = 0;
-    st = map_first_of_two(e, m, qx, qy, A, B, &first);
-    if (st != TRG_OK) return st;
-    if (first == 1) w = c;
-  }
-  *z = T.z[w];
-  return TRG_OK;
-}
-
-TrgStatus nearest_z_sync(TrgEngine *e, DevMap &m, const float *xy, size_t cnt, float *z,
-                         int32_t *found) {
-  if (!m.valid) return e->fail(TRG_ERR_NO_MAP, "nearest_z on an empty map");
-  const size_t B = 1 << 20;
-  for (size_t off = 0; off < cnt; off += B) {
-    const size_t m_ = std::min(B, cnt - off);
-    TrgStatus st = ensure_sync_scratch(e, m_);
-    if (st != TRG_OK) return st;
-    memcpy(e->sy_in.h, xy + 2 * off, m_ * 2 * sizeof(float));
-    HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 2 * sizeof(float), hipMemcpyHostToDevice,
-                             e->s_main));
-    launch_probe_nearest_z(m.view, qparams(e), e->sy_in.d, (int)m_, e->sy_f0.d, e->sy_i0.d,
-                           e->d_ctr, e->s_main);
-    HIPCHK(e, hipMemcpyAsync(e->sy_f0.h, e->sy_f0.d, m_ * sizeof(float), hipMemcpyDeviceToHost,
-                             e->s_main));
-    HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             e->s_main));
-    HIPCHK(e, hipStreamSynchronize(e->s_main));
-    HIPCHK(e, hipGetLastError());
-    memcpy(z + off, e->sy_f0.h, m_ * sizeof(float));
-    // found == 2: several map points at the same fp32 distance; ask for the reference's choice
-    std::vector<size_t> tied;
-    for (size_t i = 0; i < m_; ++i) {
-      if (e->sy_i0.h[i] == 2) tied.push_back(i);
-      if (found) found[off + i] = e->sy_i0.h[i] ? 1 : 0;
-    }
-    for (size_t i : tied) {
-      bool f = false;
-      float zz = 0;
-      st = map_nn_exact(e, m, xy[2 * (off + i)], xy[2 * (off + i) + 1], &zz, &f);
-      if (st != TRG_OK) return st;
-      if (f) z[off + i] = zz;
-    }
-  }
-  e->stats.sync_batches++;
-  return TRG_OK;
-}
-
-// The reference's slope gate (trg.cpp:269-274) evaluated with the host libm, used only for the
-// sliver the device's exact rational test could not decide.
-inline bool host_slope_gate(const TrgEngine *e, float z1, float z2, float dist) {
-  float max_slope = atan2(e->prm.height_threshold, e->prm.robot_size);
-  float slope = atan2(fabs(z1 - z2), dist);
-  return slope > max_slope;
-}
-// final status code (0..4) of an edge evaluation after resolving an uncertain gate
-inline int resolve_status(TrgEngine *e, int raw, float z1, float z2, float dist) {
-  if (raw & EDGE_GATE_UNCERTAIN) {
-    e->stats.gate_uncertain++;
-    if (host_slope_gate(e, z1, z2, dist)) return EDGE_GATE;
-  }
-  return raw & EDGE_STATUS_MASK;
-}
-
-TrgStatus edges_sync(TrgEngine *e, DevMap &m, const float *p1, const float *p2, size_t cnt,
-                     int32_t *status, int32_t *n_pts, float *weight, float *dist, bool resolve) {
-  if (!m.valid) return e->fail(TRG_ERR_NO_MAP, "edge evaluation on an empty map");
-  const size_t B = 1 << 18;
-  for (size_t off = 0; off < cnt; off += B) {
-    const size_t m_ = std::min(B, cnt - off);
-    TrgStatus st = ensure_sync_scratch(e, m_);
-    if (st != TRG_OK) return st;
-    memcpy(e->sy_in.h, p1 + 3 * off, m_ * 3 * sizeof(float));
-    memcpy(e->sy_in2.h, p2 + 3 * off, m_ * 3 * sizeof(float));
-    HIPCHK(e, hipMemcpyAsync(e->sy_in.d, e->sy_in.h, m_ * 3 * sizeof(float), hipMemcpyHostToDevice,
-                             e->s_main));
-    HIPCHK(e, hipMemcpyAsync(e->sy_in2.d, e->sy_in2.h, m_ * 3 * sizeof(float),
-                             hipMemcpyHostToDevice, e->s_main));
-    launch_edges(m.view, qparams(e), e->sy_in.d, e->sy_in2.d, (int)m_, e->sy_mid, e->sy_i0.d,
-                 e->sy_i1.d, e->sy_f0.d, e->sy_f1.d, e->d_ctr, e->s_main);
-    HIPCHK(e, hipMemcpyAsync(e->sy_i0.h, e->sy_i0.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             e->s_main));
-    HIPCHK(e, hipMemcpyAsync(e->sy_i1.h, e->sy_i1.d, m_ * sizeof(int), hipMemcpyDeviceToHost,
-                             e->s_main));
-    HIPCHK(e, hipMemcpyAsync(e->sy_f0.h, e->sy_f0.d, m_ * sizeof(float), hipMemcpyDeviceToHost,
-                             e->s_main));
-    HIPCHK(e, hipMemcpyAsync(e->sy_f1.h, e->sy_f1.d, m_ * sizeof(float), hipMemcpyDeviceToHost,
-                             e->s_main));
-    HIPCHK(e, hipStreamSynchronize(e->s_main));
-    HIPCHK(e, hipGetLastError());
-    for (size_t i = 0; i < m_; ++i) {
-      int raw = e->sy_i0.h[i];
-      int stt = raw;
-      if (resolve) {
-        stt = resolve_status(e, raw, p1[3 * (off + i) + 2], p2[3 * (off + i) + 2], e->sy_f1.h[i]);
-      }
-      if (status) status[off + i] = stt;
-      if (n_pts) n_pts[off + i] = e->sy_i1.h[i];
-      if (weight) weight[off + i] = (stt == EDGE_OK) ? e->sy_f0.h[i] : 0.0f;
-      if (dist) dist[off + i] = e->sy_f1.h[i];
-    }
-    e->stats.edge_evals_gpu += m_;
-  }
-  e->stats.sync_batches++;
-  return TRG_OK;
-}
+#include "trg_engine_probe.ipp"
 
 // the stitched rows belong to the graph they were assembled from: every change of the global graph voids them
 void invalidate_stitched(TrgEngine *e) {
@@ -1364,586 +750,9 @@ int nearest_node(TrgEngine *e, float qx, float qy) {
   return s;
 }
 
-// ---- chunk pipeline ----------------------------------------------------------------------------
-TrgStatus ensure_chunks(TrgEngine *e) {
-  const int S = e->prm.sample_num;
-  if (e->chunk_S == S && e->chunks[0].done) return TRG_OK;
-  const size_t cmax = TrgEngine::CHUNK_MAX;
-  const size_t slots = cmax * (size_t)std::max(S, 1);
-  Chunk *all_chunks[TrgEngine::NCHUNK + 1];
-  for (int i = 0; i < TrgEngine::NCHUNK; ++i) all_chunks[i] = &e->chunks[i];
-  all_chunks[TrgEngine::NCHUNK] = &e->root_chunk;
-  for (Chunk *cp : all_chunks) {
-    Chunk &c = *cp;
-    if (!c.done) {
-      HIPCHK(e, hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
-      HIPCHK(e, hipEventCreate(&c.t0));
-      HIPCHK(e, hipEventCreate(&c.t1));
-      HIPCHK(e, hipEventCreate(&c.t2));
-    }
-    HIPCHK(e, alloc_pinned(c.in_blob, 6 * cmax));
-    HIPCHK(e, alloc_pinned(c.out_blob, 2 * cmax + 6 * slots));
-    HIPCHK(e, alloc_pinned(c.mt, 4 + 4 * (size_t)MAPTIE_CAP));
-    if (c.mid_cap < slots) {
-      if (c.d_mid) (void)hipFree(c.d_mid);
-      c.d_mid = nullptr;
-      HIPCHK(e, hipMalloc((void **)&c.d_mid, edge_mid_floats(slots) * sizeof(float)));
-      c.mid_cap = slots;
-    }
-  }
-  for (EdgeBatch &b : e->ebatches) {
-    if (!b.done) {
-      HIPCHK(e, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-      HIPCHK(e, hipEventCreate(&b.t0));
-      HIPCHK(e, hipEventCreate(&b.t1));
-    }
-    HIPCHK(e, alloc_pinned(b.p1, (size_t)TrgEngine::EBATCH_MAX * 3));
-    HIPCHK(e, alloc_pinned(b.p2, (size_t)TrgEngine::EBATCH_MAX * 3));
-    HIPCHK(e, alloc_pinned(b.weight, (size_t)TrgEngine::EBATCH_MAX));
-    HIPCHK(e, alloc_pinned(b.dist, (size_t)TrgEngine::EBATCH_MAX));
-    HIPCHK(e, alloc_pinned(b.status, (size_t)TrgEngine::EBATCH_MAX));
-    if (!b.d_mid)
-      HIPCHK(e, hipMalloc((void **)&b.d_mid,
-                          edge_mid_floats(TrgEngine::EBATCH_MAX) * sizeof(float)));
-  }
-  e->chunk_S = S;
-  return TRG_OK;
-}
+#include "trg_engine_replay.ipp"
 
-TrgStatus submit_chunk(TrgEngine *e, Chunk &c, int first, int count) {
-  const int S = e->prm.sample_num;
-  c.first = first;
-  c.count = count;
-  c.carve(count, S);
-  for (int i = 0; i < count; ++i) {
-    const int id = e->queue[first + i];
-    c.node_xy.h[2 * i] = e->nx[id];
-    c.node_xy.h[2 * i + 1] = e->ny[id];
-    c.node_xyz.h[3 * i] = e->nx[id];
-    c.node_xyz.h[3 * i + 1] = e->ny[id];
-    c.node_xyz.h[3 * i + 2] = e->nz[id];
-    c.node_id.h[i] = id;
-  }
-  hipStream_t s = e->s_main;
-  HIPCHK(e, hipMemcpyAsync(c.in_blob.d, c.in_blob.h, c.in_words * sizeof(uint32_t),
-                           hipMemcpyHostToDevice, s));
-  const QueryParams q = qparams(e);
-  HIPCHK(e, hipMemsetAsync(c.mt.d, 0, sizeof(int), s));
-  HIPCHK(e, hipEventRecord(c.t0, s));
-  launch_sample_nodes(e->gmap.view, q, e->d_cos, e->d_sin, e->sampler.table_bits, e->sampler.seed,
-                      e->epoch, c.node_xy.d, c.node_id.d, count, c.n_acc.d, c.n_draws.d, c.sx.d,
-                      c.sy.d, c.sz.d, e->d_ctr, c.mt.d, (MapTieRec *)(c.mt.d + 4), s);
-  HIPCHK(e, hipEventRecord(c.t1, s));
-  launch_spec_edges(e->gmap.view, q, c.node_xyz.d, count, c.n_acc.d, c.sx.d, c.sy.d, c.sz.d,
-                    c.d_mid, c.status.d, nullptr, c.weight.d, c.dist.d, e->d_ctr, s);
-  HIPCHK(e, hipEventRecord(c.t2, s));
-  HIPCHK(e, hipMemcpyAsync(c.out_blob.h, c.out_blob.d, c.out_words * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipMemcpyAsync(c.mt.h, c.mt.d, (4 + 4 * (size_t)MAPTIE_CAP) * sizeof(int),
-                           hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipEventRecord(c.done, s));
-  c.in_flight = true;
-  e->stats.launches_sample_kernel++;
-  e->stats.launches_spec_kernel++;
-  return TRG_OK;
-}
-
-// the same launch sequence for an explicit list of node ids (the roots of updateGraph's expansions)
-TrgStatus submit_nodes(TrgEngine *e, Chunk &c, const int *ids, int count) {
-  std::vector<int> saved;
-  saved.swap(e->queue);
-  e->queue.assign(ids, ids + count);
-  const TrgStatus st = submit_chunk(e, c, 0, count);
-  e->queue.swap(saved);
-  return st;
-}
-
-TrgStatus wait_chunk(TrgEngine *e, Chunk &c) {
-  if (!c.in_flight) return TRG_OK;
-  auto t0 = Clock::now();
-  HIPCHK(e, hipEventSynchronize(c.done));
-  e->stats.ms_wait_gpu += ms_since(t0);
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, c.t0, c.t1) == hipSuccess) e->stats.ms_sample_kernel += ms;
-  if (hipEventElapsedTime(&ms, c.t1, c.t2) == hipSuccess) e->stats.ms_spec_kernel += ms;
-  c.in_flight = false;
-  // accepted samples whose elevation hung on a nearest-point tie: take the point the reference's
-  // map tree returns, and re-evaluate the parent edge if that changed the sample's z
-  const int n_mt = c.mt.h[0];
-  if (n_mt > 0) {
-    const int S = e->prm.sample_num;
-    const MapTieRec *recs = (const MapTieRec *)(c.mt.h + 4);
-    if (n_mt > MAPTIE_CAP) e->stats.map_nn_unresolved += (uint64_t)(n_mt - MAPTIE_CAP);
-    for (int k = 0; k < std::min(n_mt, MAPTIE_CAP); ++k) {
-      const MapTieRec &r = recs[k];
-      float z = 0;
-      bool found = false;
-      TrgStatus st = map_nn_exact(e, e->gmap, r.qx, r.qy, &z, &found);
-      if (st != TRG_OK) return st;
-      if (!found || !(z != c.sz.h[r.slot])) continue;
-      c.sz.h[r.slot] = z;
-      const int qi = r.slot / S;
-      const float p1[3] = {c.node_xyz.h[3 * qi], c.node_xyz.h[3 * qi + 1], c.node_xyz.h[3 * qi + 2]};
-      const float p2[3] = {r.qx, r.qy, z};
-      int32_t stt = 0;
-      float w = 0, d = 0;
-      st = edges_sync(e, e->gmap, p1, p2, 1, &stt, nullptr, &w, &d, true);
-      if (st != TRG_OK) return st;
-      c.status.h[r.slot] = stt;
-      c.weight.h[r.slot] = w;
-      c.dist.h[r.slot] = d;
-    }
-  }
-  return TRG_OK;
-}
-
-TrgStatus collect_batch(TrgEngine *e, EdgeBatch &b) {
-  if (!b.in_flight) return TRG_OK;
-  auto t0 = Clock::now();
-  HIPCHK(e, hipEventSynchronize(b.done));
-  e->stats.ms_wait_gpu += ms_since(t0);
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, b.t0, b.t1) == hipSuccess) e->stats.ms_edge_kernel += ms;
-  for (int i = 0; i < b.count; ++i) {
-    CallRec &c = e->calls[b.call_idx[i]];
-    c.dist = b.dist.h[i];
-    c.status = resolve_status(e, b.status.h[i], e->nz[c.n1], e->nz[c.n2], c.dist);
-    c.weight = (c.status == EDGE_OK) ? b.weight.h[i] : 0.0f;
-  }
-  b.in_flight = false;
-  b.count = 0;
-  return TRG_OK;
-}
-
-// ship the pending deferred wireEdge evaluations (node -> already existing node) to the GPU
-TrgStatus flush_pending(TrgEngine *e, bool all) {
-  size_t pos = 0;
-  while (e->pending_calls.size() - pos >= (all ? 1u : (size_t)TrgEngine::EBATCH_MAX)) {
-    // find a free batch buffer, collecting the oldest if none
-    EdgeBatch *b = nullptr;
-    for (EdgeBatch &cand : e->ebatches)
-      if (!cand.in_flight) {
-        b = &cand;
-        break;
-      }
-    if (!b) {
-      TrgStatus st = collect_batch(e, e->ebatches[0]);
-      if (st != TRG_OK) return st;
-      // rotate so that [0] is again the oldest
-      std::rotate(e->ebatches, e->ebatches + 1, e->ebatches + TrgEngine::NEBATCH);
-      b = &e->ebatches[TrgEngine::NEBATCH - 1];
-    }
-    const int cnt = (int)std::min<size_t>(TrgEngine::EBATCH_MAX, e->pending_calls.size() - pos);
-    b->call_idx.assign(e->pending_calls.begin() + pos, e->pending_calls.begin() + pos + cnt);
-    for (int i = 0; i < cnt; ++i) {
-      const CallRec &c = e->calls[b->call_idx[i]];
-      b->p1.h[3 * i] = e->nx[c.n1];
-      b->p1.h[3 * i + 1] = e->ny[c.n1];
-      b->p1.h[3 * i + 2] = e->nz[c.n1];
-      b->p2.h[3 * i] = e->nx[c.n2];
-      b->p2.h[3 * i + 1] = e->ny[c.n2];
-      b->p2.h[3 * i + 2] = e->nz[c.n2];
-    }
-    hipStream_t s = e->s_edge;
-    HIPCHK(e, hipMemcpyAsync(b->p1.d, b->p1.h, (size_t)cnt * 3 * sizeof(float),
-                             hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipMemcpyAsync(b->p2.d, b->p2.h, (size_t)cnt * 3 * sizeof(float),
-                             hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipEventRecord(b->t0, s));
-    launch_edges(e->gmap.view, qparams(e), b->p1.d, b->p2.d, cnt, b->d_mid, b->status.d, nullptr,
-                 b->weight.d, b->dist.d, e->d_ctr, s);
-    HIPCHK(e, hipEventRecord(b->t1, s));
-    HIPCHK(e, hipMemcpyAsync(b->status.h, b->status.d, (size_t)cnt * sizeof(int),
-                             hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipMemcpyAsync(b->weight.h, b->weight.d, (size_t)cnt * sizeof(float),
-                             hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipMemcpyAsync(b->dist.h, b->dist.d, (size_t)cnt * sizeof(float),
-                             hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipEventRecord(b->done, s));
-    b->in_flight = true;
-    b->count = cnt;
-    e->stats.launches_edge_kernel++;
-    e->stats.edge_evals_gpu += cnt;
-    pos += cnt;
-  }
-  e->pending_calls.erase(e->pending_calls.begin(), e->pending_calls.begin() + pos);
-  if (all) {
-    for (EdgeBatch &b : e->ebatches) {
-      TrgStatus st = collect_batch(e, b);
-      if (st != TRG_OK) return st;
-    }
-  }
-  return TRG_OK;
-}
-
-inline void emit_deferred(TrgEngine *e, int n1, int n2) {
-  if (n1 == n2) return;  // wireEdge returns at once (trg.cpp:255-257)
-  e->calls.push_back(CallRec{n1, n2, -1, 0.0f, 0.0f});
-  e->pending_calls.push_back((int)e->calls.size() - 1);
-  e->stats.edge_calls++;
-}
-
-// Apply the logged wireEdge() calls in program order: the dedupe of trg.cpp:255-267 and the two
-// push_backs of trg.cpp:365-368.  `from` = first call not yet applied.
-void apply_calls(TrgEngine *e, size_t from) {
-  e->edges.grow_nodes(e->nx.size());
-  for (size_t i = from; i < e->calls.size(); ++i) {
-    const CallRec &c = e->calls[i];
-    if (c.n1 == c.n2) continue;
-    if (e->edges.has(c.n1, c.n2) || e->edges.has(c.n2, c.n1)) continue;
-    if (c.status != EDGE_OK) continue;
-    e->edges.push(c.n1, c.n2, c.weight, c.dist);
-    e->edges.push(c.n2, c.n1, c.weight, c.dist);
-  }
-}
-
-// BFS expansion from the node `ref_id`, replaying trg.cpp:372-454 with GPU results.
-// `applied` is the index of the first call not yet folded into e->edges; step 3's validity test
-// needs edges of brand-new nodes only, which it derives locally.
-// pre / pre_qi: GPU results of the root already fetched (entry pre_qi of chunk *pre, used by
-// updateGraph, which fetches all its roots in bulk); the root then needs no round trip of its own.
-TrgStatus expand_bfs(TrgEngine *e, int ref_id, Chunk *pre = nullptr, int pre_qi = 0) {
-  TrgStatus st = ensure_chunks(e);
-  if (st != TRG_OK) return st;
-  const int S = e->prm.sample_num;
-  const float r = e->prm.robot_size;
-  e->queue.clear();
-  e->queue.push_back(ref_id);
-  size_t head = 0;        // next queue position to replay
-  size_t submitted = pre ? 1 : 0;  // queue positions [0, submitted) have been shipped to the GPU
-  int next_buf = 0;       // chunk buffers are used round-robin, so completion order == queue order
-  std::deque<int> inflight;  // chunk buffer indices in submission order
-  std::vector<int> range_hits;
-  std::vector<float> s3_p1, s3_p2, s3_w, s3_d;
-  std::vector<int32_t> s3_st;
-  auto t_replay = Clock::now();
-  double waited0 = e->stats.ms_wait_gpu;
-
-  // Ship queue positions [submitted, submitted+cnt) in the next free buffer.  Buffers are used
-  // round-robin and consumed in the same order, so the oldest in-flight chunk is always next.
-  auto ship = [&](size_t cnt) -> TrgStatus {
-    Chunk &c = e->chunks[next_buf];
-    TrgStatus s2 = submit_chunk(e, c, (int)submitted, (int)cnt);
-    if (s2 != TRG_OK) return s2;
-    inflight.push_back(next_buf);
-    next_buf = (next_buf + 1) % TrgEngine::NCHUNK;
-    submitted += cnt;
-    return TRG_OK;
-  };
-
-  Chunk *cur = nullptr;
-  while (head < e->queue.size()) {
-    // keep the GPU fed while the replay works: full-size chunks as soon as enough nodes are queued,
-    // a small one only when the chunk being replayed is about to run dry
-    for (;;) {
-      const size_t avail = e->queue.size() - submitted;
-      const int busy = (int)inflight.size() + (cur ? 1 : 0);
-      if (avail == 0 || busy >= TrgEngine::NCHUNK) break;
-      const size_t left = cur ? (size_t)(cur->first + cur->count) - head : 0;
-      const bool starving = inflight.empty() && left <= 16;
-      if (avail < 512 && !starving) break;
-      st = ship(std::min<size_t>(avail, TrgEngine::CHUNK_MAX));
-      if (st != TRG_OK) return st;
-    }
-    const bool use_pre = pre && head == 0;
-    if (!use_pre && (!cur || (int)head >= cur->first + cur->count)) {
-      cur = nullptr;
-      if (inflight.empty()) return e->fail(TRG_ERR_DEVICE, "replay starved (internal error)");
-      cur = &e->chunks[inflight.front()];
-      inflight.pop_front();
-      st = wait_chunk(e, *cur);
-      if (st != TRG_OK) return st;
-    }
-    Chunk *const src = use_pre ? pre : cur;
-    const int qi = use_pre ? pre_qi : (int)head - cur->first;
-    const int node = e->queue[head];
-    head++;
-    e->stats.expanded_nodes++;
-    const int n_acc = src->n_acc.h[qi];
-    e->stats.trials += src->n_draws.h[qi];
-    e->stats.samples += n_acc;
-    e->stats.edge_evals_gpu += n_acc;
-
-    for (int j = 0; j < n_acc; ++j) {
-      const int slot = qi * S + j;
-      const float sx = src->sx.h[slot], sy = src->sy.h[slot];
-      // 1. nearest existing node (trg.cpp:408-417)
-      const int ex = nearest_node(e, sx, sy);
-      if (e->nstate[ex] == TRG_NODE_INVALID) continue;
-      if (norm2f(e->nx[ex] - sx, e->ny[ex] - sy) < r) {
-        emit_deferred(e, node, ex);
-        continue;
-      }
-      // 2. new node (trg.cpp:420-426); its parent edge was evaluated speculatively on the GPU
-      const int new_state = (ref_id == 0) ? TRG_NODE_VALID : TRG_NODE_FRONTIER;
-      const float sz = src->sz.h[slot];
-      const int nn = add_node_host(e, sx, sy, sz, new_state);
-      const float dist = src->dist.h[slot];
-      const int stt = resolve_status(e, src->status.h[slot], e->nz[node], sz, dist);
-      const bool parent_ok = (stt == EDGE_OK);
-      e->calls.push_back(
-          CallRec{node, nn, stt, parent_ok ? src->weight.h[slot] : 0.0f, dist});
-      e->stats.edge_calls++;
-      bool has_edge = parent_ok;
-
-      // 3. neighbour wiring (trg.cpp:429-444), only for configs like indoor.yaml
-      if (e->step3) {
-        kd_sync(e);
-        e->kd.range(e->nx[nn], e->ny[nn], e->prm.expand_dist, range_hits);
-        const size_t first_call = e->calls.size();
-        for (int other : range_hits) {
-          if (e->nstate[other] == TRG_NODE_INVALID) continue;
-          emit_deferred(e, nn, other);
-        }
-        if (!parent_ok && e->calls.size() > first_call) {
-          // the node's fate hangs on these edges: evaluate them now (synchronous round trip)
-          const size_t m = e->calls.size() - first_call;
-          s3_p1.resize(3 * m);
-          s3_p2.resize(3 * m);
-          s3_st.resize(m);
-          s3_w.resize(m);
-          s3_d.resize(m);
-          for (size_t k = 0; k < m; ++k) {
-            const CallRec &c = e->calls[first_call + k];
-            s3_p1[3 * k] = e->nx[c.n1];
-            s3_p1[3 * k + 1] = e->ny[c.n1];
-            s3_p1[3 * k + 2] = e->nz[c.n1];
-            s3_p2[3 * k] = e->nx[c.n2];
-            s3_p2[3 * k + 1] = e->ny[c.n2];
-            s3_p2[3 * k + 2] = e->nz[c.n2];
-          }
-          st = edges_sync(e, e->gmap, s3_p1.data(), s3_p2.data(), m, s3_st.data(), nullptr,
-                          s3_w.data(), s3_d.data(), true);
-          if (st != TRG_OK) return st;
-          for (size_t k = 0; k < m; ++k) {
-            CallRec &c = e->calls[first_call + k];
-            c.status = s3_st[k];
-            c.weight = s3_w[k];
-            c.dist = s3_d[k];
-            if (c.status == EDGE_OK) has_edge = true;
-          }
-          // they are resolved: take them off the pending list (they were appended last)
-          e->pending_calls.resize(e->pending_calls.size() - m);
-        }
-      }
-
-      // 4. (trg.cpp:447-451)
-      if (!has_edge) {
-        e->nstate[nn] = TRG_NODE_INVALID;
-        e->stats.invalid_nodes++;
-        continue;
-      }
-      e->queue.push_back(nn);
-    }
-    if ((int)e->pending_calls.size() >= TrgEngine::EBATCH_MAX) {
-      st = flush_pending(e, false);
-      if (st != TRG_OK) return st;
-    }
-  }
-  e->stats.ms_replay_host += ms_since(t_replay) - (e->stats.ms_wait_gpu - waited0);
-  return TRG_OK;
-}
-
-// ---- cleanGraph (trg.cpp:491-535) ---------------------------------------------------------------
-void snapshot_csr(const TrgEngine *e, Csr &out) {
-  const size_t V = e->nx.size();
-  out.clear();
-  out.xyz.resize(3 * V);
-  out.state.resize(V);
-  out.cid.resize(V);
-  out.rowptr.resize(V + 1);
-  out.rowptr[0] = 0;
-  for (size_t i = 0; i < V; ++i) out.rowptr[i + 1] = out.rowptr[i] + (i < e->edges.deg.size() ? e->edges.deg[i] : 0);
-  const size_t E = out.rowptr[V];
-  out.col.resize(E);
-  out.w.resize(E);
-  out.dist.resize(E);
-  parallel_ranges(V, [&](size_t i0, size_t i1) {
-    for (size_t i = i0; i < i1; ++i) {
-      out.xyz[3 * i] = e->nx[i];
-      out.xyz[3 * i + 1] = e->ny[i];
-      out.xyz[3 * i + 2] = e->nz[i];
-      out.state[i] = e->nstate[i];
-      out.cid[i] = e->ncid[i];
-      int k = out.rowptr[i];
-      if (i >= e->edges.head.size()) continue;
-      for (int ed = e->edges.head[i]; ed >= 0; ed = e->edges.next[ed]) {
-        out.col[k] = e->edges.dst[ed];
-        out.w[k] = e->edges.w[ed];
-        out.dist[k] = e->edges.dist[ed];
-        ++k;
-      }
-    }
-  });
-}
-
-void clean_graph(TrgEngine *e) {
-  const bool trace = getenv("TRG_TIMING") != nullptr;
-  const auto t_cg = Clock::now();
-  auto lapc = [&](const char *what) {
-    if (trace) fprintf(stderr, "[trg cleanGraph]   %-24s %8.3f ms\n", what, ms_since(t_cg));
-  };
-  const size_t V = e->nx.size();
-  std::vector<int> old2new(V, 0);  // old2new[] default-constructs 0 in the reference too
-  std::vector<int> keep_order;     // old ids in the order they receive new ids
-  int new_id = 0;
-  // new ids follow the iteration order of the reference's unordered_map (trg.cpp:497-504)
-  std::vector<int> order;
-  node_map_order(e, order);
-  for (const int id : order) {
-    if (e->nstate[id] == TRG_NODE_INVALID || e->edges.deg[id] < 1) continue;
-    old2new[id] = new_id;
-    keep_order.push_back(id);
-    new_id++;
-  }
-  // trg.cpp:505-520 drops the edges of kept nodes that lead to a node it deletes.  A kept node has edges,
-  // so the only deleted nodes an edge can lead to are Invalid ones: "is deleted" is the state test below
-  // (no separate marking pass over the 700 k-entry edge pool).
-  lapc("renumbering");
-  const int Vn = new_id;
-  std::vector<float> x2(Vn), y2(Vn), z2(Vn);
-  std::vector<int> st2(Vn), cid2(Vn);
-  // the surviving rows in bulk on several host threads: counts, offsets, then every row copied with its
-  // targets renumbered (a 6.7 M-entry pool rebuilt push by push cost 65 ms per updateGraph at C3)
-  std::vector<int> offs((size_t)Vn + 1, 0);
-  parallel_ranges((size_t)Vn, [&](size_t k0, size_t k1) {
-    for (size_t k = k0; k < k1; ++k) {
-      const int old = keep_order[k];
-      int n = 0;
-      for (int ed = e->edges.head[old]; ed >= 0; ed = e->edges.next[ed]) n += e->nstate[e->edges.dst[ed]] != TRG_NODE_INVALID;
-      offs[k + 1] = n;
-    }
-  });
-  for (int k = 0; k < Vn; ++k) offs[k + 1] += offs[k];
-  EdgePool ep;
-  ep.alloc_rows(offs);
-  parallel_ranges((size_t)Vn, [&](size_t k0, size_t k1) {
-    for (size_t k = k0; k < k1; ++k) {
-      const int old = keep_order[k];
-      x2[k] = e->nx[old];
-      y2[k] = e->ny[old];
-      z2[k] = e->nz[old];
-      st2[k] = e->nstate[old];
-      cid2[k] = e->ncid[old];
-      int pos = offs[k];
-      for (int ed = e->edges.head[old]; ed >= 0; ed = e->edges.next[ed]) {
-        const int d = e->edges.dst[ed];
-        if (e->nstate[d] == TRG_NODE_INVALID) continue;
-        ep.dst[pos] = old2new[d];
-        ep.w[pos] = e->edges.w[ed];
-        ep.dist[pos] = e->edges.dist[ed];
-        ++pos;
-      }
-    }
-    ep.link_rows(offs, k0, k1);
-  });
-  lapc("rows copied");
-  e->last_new2old = keep_order;
-  e->nx.swap(x2);
-  e->ny.swap(y2);
-  e->nz.swap(z2);
-  e->nstate.swap(st2);
-  e->ncid.swap(cid2);
-  e->edges = std::move(ep);
-  e->node_id = Vn;
-  // new_nodes[new_id] = node for the dense new ids (trg.cpp:502), global_graph.nodes = new_nodes (:526:
-  // bucket count, policy and element order of the source are taken over -- what moving it in leaves
-  // behind); then the node tree is refilled in that map's iteration order
-  if (e->real_map_stale) {
-    MapOrderSim new_nodes;
-    new_nodes.fill((size_t)Vn);
-    e->nodes_sim.assign_from(new_nodes);
-    e->nodes_sim.iteration_order(e->kd_insert_order);
-  } else {
-    std::unordered_map<int, int> new_nodes;
-    for (int k = 0; k < Vn; ++k) new_nodes[k] = k;
-    e->order_map = std::move(new_nodes);
-    e->kd_insert_order.clear();
-    for (auto &kv : e->order_map) e->kd_insert_order.push_back(kv.first);
-  }
-  e->kd_order_dirty = false;
-  e->kd_valid = false;
-  lapc("container replica");
-  grid_rebuild(e);
-  lapc("node grid");
-  e->host_grid_valid = true;
-  e->pool_valid = true;
-}
-
-void read_counters(TrgEngine *e) {
-  std::vector<DeviceCounters> h(COUNTER_SHARDS);
-  if (hipMemcpy(h.data(), e->d_ctr, COUNTER_SHARDS * sizeof(DeviceCounters),
-                hipMemcpyDeviceToHost) == hipSuccess) {
-    unsigned long long sh = 0, eh = 0, ph = 0, ties = 0;
-    for (const DeviceCounters &c : h) {
-      sh += c.sample_hits;
-      eh += c.edge_hits;
-      ph += c.spec_hits;
-      ties += c.nn_ties;
-    }
-    e->stats.bytes_sample_kernel = 12ull * (sh + e->lv_hits_sample);
-    e->stats.bytes_edge_kernel = 12ull * eh;
-    e->stats.bytes_spec_kernel = 12ull * (ph + e->lv_hits_spec);
-    e->stats.map_nn_ties += ties;
-  }
-}
-
-// ---- local graph (trg.cpp:211-231) ---------------------------------------------------------------
-// membership of the local graph (trg.cpp:211-231): n[i] != 0 iff a local-map point lies within
-// robot_size / 2 of node i (a disc-emptiness probe); only nodes inside the local map's bounding box
-// (grown by that radius) can have one
-TrgStatus local_membership(TrgEngine *e, std::vector<int32_t> &n) {
-  const size_t V = e->nx.size();
-  n.assign(V, 0);
-  if (!e->lmap.valid || V == 0) return TRG_OK;
-  const float rr = (float)(e->prm.robot_size * 0.5) * 1.01f + 1e-4f;
-  const float bx0 = e->lmap.bounds[0] - rr, by0 = e->lmap.bounds[1] - rr;
-  const float bx1 = e->lmap.bounds[2] + rr, by1 = e->lmap.bounds[3] + rr;
-  std::vector<int> cand;
-  std::vector<float> xy;
-  for (size_t i = 0; i < V; ++i)
-    if (e->nx[i] >= bx0 && e->nx[i] <= bx1 && e->ny[i] >= by0 && e->ny[i] <= by1) {
-      cand.push_back((int)i);
-      xy.push_back(e->nx[i]);
-      xy.push_back(e->ny[i]);
-    }
-  if (cand.empty()) return TRG_OK;
-  std::vector<int32_t> nc(cand.size(), 0);
-  TrgStatus st = collision_sync(e, e->lmap, 0.0f, xy.data(), cand.size(), nullptr, nullptr, nc.data(), e->s_aux,
-                                (float)(e->prm.robot_size * 0.5));
-  if (st != TRG_OK) return st;
-  for (size_t k = 0; k < cand.size(); ++k) n[cand[k]] = nc[k];
-  return TRG_OK;
-}
-
-// member: the membership flags if the caller already has them (updateGraph probes before its host-side
-// cleanGraph, while the GPU is still awake: after ~10 ms without work the first launch takes ~2 ms)
-TrgStatus set_local_graph(TrgEngine *e, const std::vector<int32_t> *member = nullptr) {
-  e->local_nodes.clear();
-  e->lkd.clear();
-  const size_t V = e->nx.size();
-  if (V == 0) {
-    e->local_map.clear();
-    return TRG_OK;
-  }
-  std::vector<int32_t> own;
-  if (!member || member->size() != V) {
-    TrgStatus st = local_membership(e, own);
-    if (st != TRG_OK) return st;
-    member = &own;
-  }
-  const std::vector<int32_t> &n = *member;
-  e->local_map.clear();  // resetGraph("local"): clear() keeps the bucket array, as the reference's does
-  std::vector<int> global_order;
-  node_map_order(e, global_order);
-  for (int id : global_order) {
-    if (n[id] == 0) continue;
-    e->local_map[id] = id;
-    e->lkd.insert(e->nx[id], e->ny[id], id);
-  }
-  for (auto &kv : e->local_map) e->local_nodes.push_back(kv.first);
-  return TRG_OK;
-}
+#include "trg_engine_clean.ipp"
 
 }  // namespace
 
@@ -2581,348 +1390,12 @@ TrgStatus trg_engine_load_json(TrgEngine *e, const char *path) {
   return TRG_OK;
 }
 
-// ---- planning (host A*, trg.cpp:537-565, 603-690) ------------------------------------------------
+// ---- planning (host A*, trg.cpp:537-565, 603-690): trg_engine_plan.ipp ----------------------------
 }  // extern "C"
 
-namespace {
-
-// positions in the node tree's insertion order (cleanGraph refills the tree in the node map's iteration
-// order, trg.cpp:525-530): only built when an answer really hangs on the tree's shape
-void ensure_kd_order_arrays(TrgEngine *e) {
-  if (e->kdo_version == e->graph_version) return;
-  materialize_kd_order(e);
-  const size_t K = e->kd_insert_order.size();
-  e->kdo_x.resize(K);
-  e->kdo_y.resize(K);
-  e->kdo_index.assign(e->nx.size(), -1);
-  for (size_t k = 0; k < K; ++k) {
-    const int id = e->kd_insert_order[k];
-    e->kdo_x[k] = e->nx[id];
-    e->kdo_y[k] = e->ny[id];
-    e->kdo_index[id] = (int)k;
-  }
-  e->kdo_version = e->graph_version;
-}
-
-// kd_nearest2 on node_tree (trg.cpp:615): the grid answers; an exact fp32 distance tie goes to the
-// tree-order argument of kd_tie_winner (no tree is built)
-int plan_nearest_node(TrgEngine *e, float qx, float qy, std::vector<int> &tied) {
-  bool tie = false;
-  int s = e->grid.nearest(qx, qy, &tie);
-  if (!tie || s < 0) return s;
-  e->stats.nn_ties++;
-  e->grid.tied_set(qx, qy, e->grid.dist2(s, qx, qy), tied);
-  ensure_kd_order_arrays(e);
-  for (int &t : tied) t = e->kdo_index[t];
-  std::sort(tied.begin(), tied.end());
-  const int w = kd_tie_winner(e->kdo_x.data(), e->kdo_y.data(), (int)e->kdo_x.size(), qx, qy, tied);
-  return e->kd_insert_order[w];
-}
-
-// First item of kd_nearest_range2(node_tree, goal, robot_size) (trg.cpp:544-546), or -1 when the set is
-// empty: the hit set comes from the grid; with several hits the reference takes the one its walk reaches
-// LAST (the result list is filled at the head).  A hit within rounding of the radius sends the question
-// to the tree replica.
-int plan_first_range_hit(TrgEngine *e, float qx, float qy, float r, std::vector<int> &hits) {
-  bool doubt = false;
-  e->grid.range_set(qx, qy, r, hits, &doubt);
-  if (doubt) {
-    kd_sync(e);
-    e->kd.range(qx, qy, r, hits);
-    return hits.empty() ? -1 : hits[0];
-  }
-  if (hits.empty()) return -1;
-  if (hits.size() == 1) return hits[0];
-  ensure_kd_order_arrays(e);
-  const int K = (int)e->kdo_x.size();
-  int last = e->kdo_index[hits[0]];
-  for (size_t i = 1; i < hits.size(); ++i) {
-    const int h = e->kdo_index[hits[i]];
-    if (kd_range_first_of_two(e->kdo_x.data(), e->kdo_y.data(), K, qx, qy, last, h) == last) last = h;
-  }
-  return e->kd_insert_order[last];
-}
-
-// setGoal (trg.cpp:537-565) without side effects: the goal node and whether it lies within robot_size
-void plan_goal_node(TrgEngine *e, PlanScratch &ps, const float goal_xyz[3], int *goal, bool *known) {
-  const int hit = plan_first_range_hit(e, goal_xyz[0], goal_xyz[1], e->prm.robot_size, ps.hits);
-  if (hit >= 0) {
-    *goal = hit;
-    *known = true;
-    return;
-  }
-  // nearest node by the float norm, first in the node map's iteration order among equals (trg.cpp:549-557)
-  float min_dist = std::numeric_limits<float>::max();
-  int g = -1;
-  std::vector<int> map_order;
-  node_map_order(e, map_order);
-  for (int id : map_order) {
-    const float d = norm2f(e->nx[id] - goal_xyz[0], e->ny[id] - goal_xyz[1]);
-    if (d < min_dist) {
-      min_dist = d;
-      g = id;
-    }
-  }
-  *goal = g;
-  *known = false;
-}
-
-// planSafePath (trg.cpp:603-690) on the CSR of the global graph: a row's entries are the node's edges in
-// the reference's push order, the heap is std::push_heap / std::pop_heap with the reference's comparator
-// (f_cost greater-than), so equal-cost ties fall exactly as in the reference's std::priority_queue.
-TrgStatus plan_on_csr(TrgEngine *e, PlanScratch &ps, int start, int goal, float *path_xyz, int32_t max_points,
-                      TrgPathInfo *info) {
-  const Csr &G = e->csr_global;
-  const size_t V = e->nx.size();
-  const int32_t *rowptr = G.rowptr.data(), *col = G.col.data();
-  const float *ew = G.w.data(), *ed = G.dist.data();
-  const float *nx = e->nx.data(), *ny = e->ny.data();
-  const int *nstate = e->nstate.data();
-  ps.begin(V);
-  const uint32_t gen = ps.gen;
-  std::vector<PlanScratch::Opt> &pool = ps.pool;
-  std::vector<int> &heap = ps.heap;
-  auto cmp = [&pool](int a, int b) { return pool[a].f > pool[b].f; };
-  const float gx = nx[goal], gy = ny[goal];
-  const double sf = e->prm.safety_factor;
-
-  info->direct_dist = norm2f(gx - nx[start], gy - ny[start]);
-  {
-    const double g_cost = 0.0;
-    const double f_cost = g_cost + info->direct_dist;
-    pool.push_back(PlanScratch::Opt{start, -1, (float)f_cost, (float)g_cost});
-    heap.push_back(0);
-    ps.open_gen[start] = gen;
-    ps.open_idx[start] = 0;
-  }
-  while (!heap.empty()) {
-    std::pop_heap(heap.begin(), heap.end(), cmp);
-    const int oi = heap.back();
-    heap.pop_back();
-    const PlanScratch::Opt cur = pool[oi];
-    ps.open_gen[cur.id] = 0;  // open_check.erase(current id)
-
-    if (cur.id == goal) {
-      std::vector<int> &chain = ps.chain;
-      chain.clear();
-      float sum_dist = 0.0, sum_weight = 0.0;
-      for (int node = oi; node >= 0; node = pool[node].parent) {
-        const PlanScratch::Opt &o = pool[node];
-        if (o.parent >= 0) {
-          const int pid = pool[o.parent].id;
-          for (int k = rowptr[o.id]; k < rowptr[o.id + 1]; ++k)
-            if (col[k] == pid) {
-              sum_dist += ed[k];
-              sum_weight += ew[k];
-              break;
-            }
-        }
-        chain.push_back(o.id);
-      }
-      const float avg_weight = sum_weight / chain.size();
-      std::reverse(chain.begin(), chain.end());
-      info->path_length = sum_dist;
-      info->avg_risk = avg_weight;
-      info->num_points = (int32_t)chain.size();
-      if (path_xyz) {
-        const int m = std::min<int>((int)chain.size(), max_points);
-        for (int i = 0; i < m; ++i) {
-          path_xyz[3 * i] = nx[chain[i]];
-          path_xyz[3 * i + 1] = ny[chain[i]];
-          path_xyz[3 * i + 2] = e->nz[chain[i]];
-        }
-      }
-      return TRG_OK;
-    }
-
-    ps.close_gen[cur.id] = gen;
-    for (int k = rowptr[cur.id]; k < rowptr[cur.id + 1]; ++k) {
-      const int dst = col[k];
-      if (dst < 0 || dst >= (int)V) continue;
-      if (ps.close_gen[dst] == gen || nstate[dst] == TRG_NODE_INVALID) continue;
-      const double next_g = cur.g + (sf * ew[k] + 1) * ed[k];
-      const double next_f = next_g + norm2f(gx - nx[dst], gy - ny[dst]);
-      pool.push_back(PlanScratch::Opt{dst, oi, (float)next_f, (float)next_g});
-      const int ni = (int)pool.size() - 1;
-      if (ps.open_gen[dst] != gen || pool[ni].g < pool[ps.open_idx[dst]].g) {
-        heap.push_back(ni);
-        std::push_heap(heap.begin(), heap.end(), cmp);
-        ps.open_gen[dst] = gen;
-        ps.open_idx[dst] = ni;
-      }
-    }
-  }
-  return TRG_ERR_NOT_FOUND;
-}
-
-// common head of plan / plan_batch: graph present, CSR rows and node grid current
-TrgStatus plan_prepare(TrgEngine *e) {
-  const size_t V = e->nx.size();
-  if (V == 0) return e->fail(TRG_ERR_NO_GRAPH, "graph is empty");
-  const Csr &G = e->csr_global;
-  if (G.rowptr.size() != V + 1 || G.state.size() != V) {
-    if (!e->pool_valid) return e->fail(TRG_ERR_NO_GRAPH, "no CSR of the current graph");
-    snapshot_csr(e, e->csr_global);
-  }
-  ensure_host_grid(e);
-  if (!e->plan_scratch) e->plan_scratch = new PlanScratch();
-  return TRG_OK;
-}
-
-}  // namespace
+#include "trg_engine_plan.ipp"
 
 extern "C" {
-
-TrgStatus trg_engine_plan(TrgEngine *e, const float start_xy[2], const float goal_xyz[3],
-                          float *path_xyz, int32_t max_points, TrgPathInfo *info) {
-  if (!e || !start_xy || !goal_xyz || !info) return TRG_ERR_INVALID_ARG;
-  info->direct_dist = info->path_length = info->avg_risk = 0.0f;
-  info->num_points = 0;
-  TrgStatus st = plan_prepare(e);
-  if (st != TRG_OK) return st;
-  PlanScratch &ps = *e->plan_scratch;
-  // setGoal
-  e->goal_pose2d[0] = goal_xyz[0];
-  e->goal_pose2d[1] = goal_xyz[1];
-  plan_goal_node(e, ps, goal_xyz, &e->goal_node, &e->goal_known);
-  const int start = plan_nearest_node(e, start_xy[0], start_xy[1], ps.tied);
-  st = plan_on_csr(e, ps, start, e->goal_node, path_xyz, max_points, info);
-  if (st == TRG_ERR_NOT_FOUND) return e->fail(TRG_ERR_NOT_FOUND, "no path");
-  return st;
-}
-
-// m consecutive planSafePath calls.  The searches are independent and only read the graph: the start /
-// goal nodes are looked up in call order (the goal state the last call leaves is the reference's), the
-// searches themselves run on up to 8 host threads, each with its own scratch.
-TrgStatus trg_engine_plan_batch(TrgEngine *e, const float *starts_xy, const float *goals_xyz,
-                                size_t m, float *path_xyz, int32_t path_cap, int32_t *offsets,
-                                TrgPathInfo *infos) {
-  if (!e || !offsets || (m && (!starts_xy || !goals_xyz || !infos)))
-    return TRG_ERR_INVALID_ARG;
-  if (path_cap < 0 || (path_cap > 0 && !path_xyz)) return e->fail(TRG_ERR_INVALID_ARG, "path buffer");
-  offsets[0] = 0;
-  if (m == 0) return TRG_OK;
-  TrgStatus st = plan_prepare(e);
-  if (st != TRG_OK) return st;
-  PlanScratch &ps0 = *e->plan_scratch;
-  std::vector<int> starts(m), goals(m);
-  for (size_t k = 0; k < m; ++k) {
-    infos[k].direct_dist = infos[k].path_length = infos[k].avg_risk = 0.0f;
-    infos[k].num_points = 0;
-    e->goal_pose2d[0] = goals_xyz[3 * k];
-    e->goal_pose2d[1] = goals_xyz[3 * k + 1];
-    plan_goal_node(e, ps0, goals_xyz + 3 * k, &e->goal_node, &e->goal_known);
-    goals[k] = e->goal_node;
-    starts[k] = plan_nearest_node(e, starts_xy[2 * k], starts_xy[2 * k + 1], ps0.tied);
-  }
-  std::vector<std::vector<float>> paths(m);
-  std::vector<TrgStatus> sts(m, TRG_OK);
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const size_t nthr = std::min<size_t>(std::min<size_t>(m, 8), hw);
-  auto work = [&](size_t t, PlanScratch &ps) {
-    for (size_t k = t; k < m; k += nthr) {
-      TrgPathInfo probe;
-      probe.direct_dist = probe.path_length = probe.avg_risk = 0.0f;
-      probe.num_points = 0;
-      sts[k] = plan_on_csr(e, ps, starts[k], goals[k], nullptr, 0, &probe);
-      if (sts[k] == TRG_OK) {
-        paths[k].resize(3 * (size_t)probe.num_points);
-        for (int i = 0; i < probe.num_points; ++i) {
-          const int id = ps.chain[i];
-          paths[k][3 * i] = e->nx[id];
-          paths[k][3 * i + 1] = e->ny[id];
-          paths[k][3 * i + 2] = e->nz[id];
-        }
-      }
-      infos[k] = probe;
-    }
-  };
-  if (nthr <= 1) {
-    work(0, ps0);
-  } else {
-    std::vector<PlanScratch> extra(nthr - 1);
-    std::vector<std::thread> thr;
-    for (size_t t = 1; t < nthr; ++t) thr.emplace_back(work, t, std::ref(extra[t - 1]));
-    work(0, ps0);
-    for (auto &th : thr) th.join();
-  }
-  int32_t used = 0;
-  for (size_t k = 0; k < m; ++k) {
-    if (sts[k] != TRG_OK && sts[k] != TRG_ERR_NOT_FOUND) return e->fail(sts[k], "plan_batch");
-    if (sts[k] == TRG_ERR_NOT_FOUND) infos[k].num_points = 0;
-    const int32_t room = path_cap - used;
-    const int32_t take = std::min<int32_t>(infos[k].num_points, room);
-    if (take > 0) memcpy(path_xyz + 3 * (size_t)used, paths[k].data(), 3 * (size_t)take * sizeof(float));
-    used += std::max<int32_t>(take, 0);
-    offsets[k + 1] = used;
-  }
-  return TRG_OK;
-}
-
-// reference: TRG::checkReadched (sic) trg.cpp:567-574 and TRG::checkReplan trg.cpp:576-601
-int32_t trg_engine_check_reached(TrgEngine *e, const float pos_xy[2]) {
-  if (!e || !pos_xy) return 0;
-  const float dist = norm2f(e->goal_pose2d[0] - pos_xy[0], e->goal_pose2d[1] - pos_xy[1]);
-  return dist < e->prm.goal_tolerance ? 1 : 0;
-}
-
-int32_t trg_engine_check_replan(TrgEngine *e, const float pos_xy[2], const float *path_xyz,
-                                int32_t n_path) {
-  if (!e || !pos_xy) return 0;
-  if (e->goal_node < 0 || e->goal_node >= (int)e->nx.size()) return 0;
-  const int g = e->goal_node;
-  const float dist2subgoal = norm2f(e->nx[g] - pos_xy[0], e->ny[g] - pos_xy[1]);
-  if (!e->goal_known && dist2subgoal < e->prm.goal_tolerance) return 1;
-  if (!e->goal_known && e->nstate[g] != TRG_NODE_FRONTIER) return 1;
-  ensure_host_grid(e);
-  std::vector<int> hits;
-  for (int i = 0; i < n_path; ++i) {  // (the node grid answers; the tree replica only within rounding of the radius)
-    int w = e->grid.within(path_xyz[3 * i], path_xyz[3 * i + 1], e->prm.robot_size);
-    if (w < 0) {
-      kd_sync(e);
-      e->kd.range(path_xyz[3 * i], path_xyz[3 * i + 1], e->prm.robot_size, hits);
-      w = hits.empty() ? 0 : 1;
-    }
-    if (!w) return 1;
-  }
-  return 0;
-}
-
-int32_t trg_engine_refine_path(const float *in_xyz, int32_t n_in, float *out_xyz, int32_t max_out) {
-  if (!in_xyz || n_in <= 0) return 0;
-  // point_between == 1: p0,p1,p1,p2,p2,...  then a 3-tap mean, last point passed through
-  std::vector<float> dense;
-  for (int i = 0; i + 1 < n_in; ++i) {
-    dense.insert(dense.end(), in_xyz + 3 * i, in_xyz + 3 * i + 3);
-    dense.insert(dense.end(), in_xyz + 3 * i + 3, in_xyz + 3 * i + 6);
-  }
-  const int nd = (int)(dense.size() / 3);
-  int written = 0;
-  for (int i = 0; i < nd; ++i) {
-    float o[3];
-    if (i == nd - 1) {
-      o[0] = dense[3 * i];
-      o[1] = dense[3 * i + 1];
-      o[2] = dense[3 * i + 2];
-    } else {
-      float sum[3] = {0.0f, 0.0f, 0.0f};
-      int cnt = 0;
-      for (int j = i - 1; j < i + 2; ++j) {
-        if (j < 0 || j >= nd) continue;
-        for (int k = 0; k < 3; ++k) sum[k] += dense[3 * j + k];
-        cnt++;
-      }
-      for (int k = 0; k < 3; ++k) o[k] = sum[k] / cnt;
-    }
-    if (out_xyz && written < max_out) {
-      out_xyz[3 * written] = o[0];
-      out_xyz[3 * written + 1] = o[1];
-      out_xyz[3 * written + 2] = o[2];
-    }
-    written++;
-  }
-  return written;
-}
 
 // ---- probes --------------------------------------------------------------------------------------
 TrgStatus trg_engine_is_collision_batch(TrgEngine *e, TrgKind map, float threshold, const float *xy,

@@ -100,7 +100,7 @@ def build_library(force=False):
     import glob
     # every source the build reads: a stale library must never pass for the tree's code
     srcs = []
-    for pat in ("*.hip", "*.inc", "*.h", "*.cpp", "*.sh"):
+    for pat in ("*.hip", "*.inc", "*.ipp", "*.h", "*.cpp", "*.sh"):
         srcs += glob.glob(os.path.join(CSRC, pat))
     srcs += glob.glob(os.path.normpath(os.path.join(CSRC, "..", "..", "include", "*")))
     stale = force or not os.path.exists(LIB_PATH) or not glob.glob(os.path.join(_HERE, "_trg_pybind*.so"))
