@@ -45,8 +45,8 @@ def test_product_does_not_touch_the_oracle():
     pkg = os.path.join(ROOT, "trg-planner_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
+            if f.endswith((".py", ".cpp", ".hip", ".inc", ".ipp", ".h", ".hpp", ".sh")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_api" not in txt and "libtrg_oracle" not in txt, os.path.join(dp, f)
                 assert "/root/reference" not in txt.replace("/root/reference/", "REF/") or f.endswith(
-                    (".hip", ".py", ".cpp", ".h")), f
+                    (".hip", ".inc", ".ipp", ".py", ".cpp", ".h", ".hpp")), f
