@@ -23,6 +23,7 @@ tiled CPU oracle and the CPU gloo test.
 from __future__ import annotations
 
 import os
+import sys
 
 import numpy as np
 
@@ -130,9 +131,25 @@ def stitch_device(eng, my_tile, core, cols, rows, dist=None, gather_dev=None):
     if (dist is not None and dist.is_initialized() and gather_dev is None and dist.get_world_size() == ntiles
             and (ntiles > 1 or os.environ.get("TRG_FORCE_COLLECTIVES"))
             and os.environ.get("TRG_NATIVE_EXCHANGE", "1") != "0" and dist.get_rank() == my_tile):
-        native_comm(eng, dist)
-        nb, nc = eng.stitch_exchange(core, cols, rows)
-        return dict(n_boundary=nb, n_cross=nc, node_offsets=None, backend="rccl-native")
+        # The engine's communicator is set up once; whether that worked is agreed on by all ranks (a rank that
+        # could not open RCCL or join must not leave the others waiting in the first all-gather): if any of
+        # them failed, every rank keeps the exchanges in torch.distributed (below) for this engine.
+        ok = getattr(eng, "_native_ok", None)
+        if ok is None:
+            from ._engine import TrgError
+            try:
+                native_comm(eng, dist)
+                mine = 1
+            except (TrgError, OSError) as ex:
+                print(f"[trg tiled] rank {dist.get_rank()}: native RCCL exchange unavailable ({ex}); "
+                      "the exchanges stay in torch.distributed", file=sys.stderr, flush=True)
+                mine = 0
+            flag = torch.tensor([mine], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = eng._native_ok = bool(int(flag.item()))
+        if ok:
+            nb, nc = eng.stitch_exchange(core, cols, rows)
+            return dict(n_boundary=nb, n_cross=nc, node_offsets=None, backend="rccl-native")
     dev = torch.device("cuda", torch.cuda.current_device())
     gdev = dev if gather_dev is None else gather_dev
     bufs = getattr(eng, "_stitch_bufs", None)  # device scratch kept with the engine, grown on demand
