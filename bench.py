@@ -58,7 +58,7 @@ def kernel_source_sha():
     h = hashlib.sha256()
     c = os.path.join(ROOT, "trg-planner_amd", "csrc")
     for f in sorted(glob.glob(os.path.join(c, "*.hip")) + glob.glob(os.path.join(c, "*.inc")) +
-                    [os.path.join(c, "trg_kernels.h")]):
+                    [os.path.join(c, "trg_kernels.h"), os.path.join(c, "build.sh")]):  # (the flags they are built with)
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()

@@ -78,7 +78,7 @@ if traffic:
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trg-planner_amd", "csrc")
     h = hashlib.sha256()
     for fsrc in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.inc")) +
-                       [os.path.join(csrc, "trg_kernels.h")]):
+                       [os.path.join(csrc, "trg_kernels.h"), os.path.join(csrc, "build.sh")]):
         h.update(os.path.basename(fsrc).encode())
         h.update(open(fsrc, "rb").read())
     out_j["kernel_source_sha256"] = h.hexdigest()
