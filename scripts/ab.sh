@@ -25,6 +25,6 @@ for i in 1 2 3; do
     if [ "$lib" = "product" ]; then libpath="$R/trg-planner_amd/csrc/libtrg_engine.so"; else libpath="$R/ab/$lib"; fi
     envs=("TRG_ENGINE_LIB=$libpath" "TRG_BENCH_FAST=1")
     for ((k=1; k<${#parts[@]}; k++)); do envs+=("${parts[$k]}"); done
-    env "${envs[@]}" python3 "$R/bench.py" --steps "${AB_STEPS:-10}" --warmup 2 --no-cpu-baseline 2>/dev/null | python3 /tmp/ab_fmt.py "$name"
+    env "${envs[@]}" timeout -k 10 "${AB_TIMEOUT:-150}" python3 "$R/bench.py" --steps "${AB_STEPS:-10}" --warmup 2 --no-cpu-baseline 2>/dev/null | python3 /tmp/ab_fmt.py "$name"
   done
 done
