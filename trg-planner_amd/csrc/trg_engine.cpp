@@ -968,6 +968,7 @@ TrgStatus trg_engine_set_local_map(TrgEngine *e, const float start_xy[2], const 
 TrgStatus trg_engine_reset_map(TrgEngine *e, TrgKind kind) {
   REQUIRE_DEVICE(e);
   DevMap *m = pick_map(e, kind);
+  m->top_wait();  // (a helper preparing the map's tie-break structures still reads it)
   m->n = 0;
   m->valid = false;
   return TRG_OK;

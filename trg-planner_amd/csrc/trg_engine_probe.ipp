@@ -156,12 +156,19 @@ void start_map_top(TrgEngine *e, DevMap &m) {
   hipEvent_t ev = e->top_ev;
   const float *src = e->top_xy_h;
   DevMap *mp = &m;
-  m.top_thread = std::thread([dev, ev, src, mp, M] {
-    (void)hipSetDevice(dev);
-    if (hipEventSynchronize(ev) != hipSuccess) return;
-    mp->top_xy.assign(src, src + (size_t)M * 2);
-    insert_map_top(*mp, M);
-  });
+  try {  // (no exception may leave the C ABI: without the helper the top is built on demand, ensure_map_top)
+    m.top_thread = std::thread([dev, ev, src, mp, M] {
+      (void)hipSetDevice(dev);
+      if (hipEventSynchronize(ev) != hipSuccess) return;
+      try {
+        mp->top_xy.assign(src, src + (size_t)M * 2);
+        insert_map_top(*mp, M);
+      } catch (...) {
+        mp->top_m = 0;
+      }
+    });
+  } catch (...) {
+  }
 }
 
 TrgStatus map_first_of_two(TrgEngine *e, DevMap &m, float qx, float qy, const TiePoint &A,
