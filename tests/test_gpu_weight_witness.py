@@ -5,11 +5,11 @@ literally in fp32 with plain left-to-right sums (the default), and with the same
 fp64 (`set_cov_f64`).  The engine accumulates the covariance in fp64, so:
 
 * against the fp64 witness its weights are the SAME FLOATS on every edge of every case tried (the randomised
-  soak `scripts/soak_parity.py`: 0 of 4.8 M directed entries differ, `profiles/r03_soak_parity.txt`);
+  soak `scripts/soak_parity.py`: 0 of 13 M directed entries differ, `profiles/r03_soak_parity.txt`);
 * against the fp32 restatement they lie within the north-star tolerance of 1e-5 -- except on about one edge
   per million, where the covariance is nearly degenerate and the fp32 sums' own rounding moves the weight by
   1-2e-5.  The reference's Eigen build sums in yet another (packet) order, so it cannot agree with either
-  restatement better than that on such an edge; the soak found five of them in 230 random cases, and round 2's
+  restatement better than that on such an edge; the soak found six of them in 320 random cases, and round 2's
   code has the very same five.
 
 The cases below are two of those five (small: they run in a second) and a plain one.
